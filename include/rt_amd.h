@@ -1,0 +1,253 @@
+/*
+ * rt_amd.h -- C ABI of the MI355X (gfx950) path-tracing hot path.
+ *
+ * The reference (Jiaqi1song/RayTracing) has no FFI/plugin layer: its boundary is the C++ source-level
+ * scene API plus one call, camera::render(world, lights) (src/cpu/camera.h:157).  The host-side mirror
+ * of that API (include/rtamd/) flattens the object graph into the plain structs below and calls the
+ * entry points declared here.  Everything is plain C: fixed-width scalars, pointers and sizes; no C++
+ * or torch types cross this boundary.
+ *
+ * Conventions: every call returns RT_OK (0) or a negative status and never exits the process
+ * (the reference exit()s: color.h:76-79).  The caller owns every host buffer it passes; the library owns
+ * device memory behind rt_scene / rt_ctx.  One rt_ctx is used from one host thread at a time.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_AMD_ABI_VERSION 1
+
+/* ---- status codes ---------------------------------------------------------------------------- */
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,     /* bad argument / malformed scene description              */
+    RT_ERR_HIP = -2,         /* a HIP runtime call failed (see rt_last_error)            */
+    RT_ERR_UNSUPPORTED = -3, /* legal reference scene graph the device path cannot take  */
+    RT_ERR_NOMEM = -4
+};
+
+/* ---- flat scene description -------------------------------------------------------------------
+ * A scene is the reference's hittable graph written as an array of nodes.  Node ids are the
+ * "primitive ids" reported by rt_trace_batch.  All geometry is IEEE double exactly as the reference
+ * constructors compute it, so that the f64 parity path reproduces reference arithmetic bit for bit.
+ */
+enum rt_node_kind {
+    RT_NODE_BVH = 0,       /* bvh_node            src/cpu/bvh.h:11      a=left node, b=right node            */
+    RT_NODE_LIST = 1,      /* hittable_list       hittable_list.h:10    a=first slot in child_index, b=count  */
+    RT_NODE_TRANSLATE = 2, /* translate           hittable.h:45         a=child node, p[0..2]=offset          */
+    RT_NODE_ROTATE_Y = 3,  /* rotate_y            hittable.h:76         a=child node, p[0]=sin, p[1]=cos      */
+    RT_NODE_MEDIUM = 4,    /* constant_medium     constant_medium.h:9   a=boundary node, b=material (isotropic), p[0]=-1/density */
+    RT_NODE_SPHERE = 5,    /* sphere              sphere.h:8            a=index into spheres                  */
+    RT_NODE_QUAD = 6,      /* quad                quad.h:8              a=index into quads                    */
+    RT_NODE_TRIANGLE = 7   /* triangle            triangle.h:13         a=index into triangles                */
+};
+
+typedef struct rt_node {
+    int32_t kind;
+    int32_t a;
+    int32_t b;
+    int32_t reserved;
+    double bbox[6]; /* bounding_box(): x.min,x.max,y.min,y.max,z.min,z.max */
+    double p[4];
+} rt_node; /* 96 bytes */
+
+typedef struct rt_sphere { /* sphere.h:11-27: center is a ray (center1, center2-center1) */
+    double center[3];
+    double dcenter[3];
+    double radius;
+    int32_t mat; /* -1 = null material (legal for light shapes, cpuRenderer.cpp:133-135) */
+    int32_t reserved;
+} rt_sphere; /* 64 bytes */
+
+typedef struct rt_quad { /* quad.h:10-21; derived fields stored as the ctor computed them */
+    double Q[3];
+    double u[3];
+    double v[3];
+    double w[3];
+    double normal[3];
+    double D;
+    double area;
+    int32_t mat;
+    int32_t reserved;
+} rt_quad; /* 144 bytes */
+
+typedef struct rt_triangle { /* triangle.h:15-21,82-86 */
+    double v0[3];
+    double v1[3];
+    double v2[3];
+    double normal[3];
+    int32_t mat;
+    int32_t cull; /* backCulling flag (build_mesh passes false: triangle.h:108) */
+} rt_triangle; /* 104 bytes */
+
+enum rt_material_kind {
+    RT_MAT_LAMBERTIAN = 0,    /* material.h:39  tex                     */
+    RT_MAT_METAL = 1,         /* material.h:62  albedo, fuzz (<=1)      */
+    RT_MAT_DIELECTRIC = 2,    /* material.h:84  ior                     */
+    RT_MAT_DIFFUSE_LIGHT = 3, /* material.h:124 tex                     */
+    RT_MAT_ISOTROPIC = 4      /* material.h:141 tex                     */
+};
+
+typedef struct rt_material {
+    int32_t kind;
+    int32_t tex; /* texture id or -1 */
+    double albedo[3];
+    double fuzz;
+    double ior;
+} rt_material; /* 48 bytes */
+
+enum rt_texture_kind {
+    RT_TEX_SOLID = 0,   /* texture.h:16  color                                            */
+    RT_TEX_CHECKER = 1, /* texture.h:31  scale = inv_scale, a = even texture, b = odd     */
+    RT_TEX_IMAGE = 2,   /* texture.h:56  a = image id (or -1: no data -> cyan)            */
+    RT_TEX_NOISE = 3    /* texture.h:81  scale, a = perlin id                             */
+};
+
+typedef struct rt_texture {
+    int32_t kind;
+    int32_t a;
+    int32_t b;
+    int32_t reserved;
+    double color[3];
+    double scale;
+} rt_texture; /* 48 bytes */
+
+typedef struct rt_image { /* rtw_image bdata: linearised RGB8, row-major (stb_image_utils.h:95-109) */
+    int32_t width;
+    int32_t height;
+    int64_t offset; /* byte offset into image_bytes */
+} rt_image;
+
+typedef struct rt_perlin { /* perlin.h:52-57 */
+    double randvec[256][3];
+    int32_t perm_x[256];
+    int32_t perm_y[256];
+    int32_t perm_z[256];
+} rt_perlin;
+
+typedef struct rt_scene_desc {
+    int32_t abi_version; /* RT_AMD_ABI_VERSION */
+    int32_t world_root;  /* node id of `world`  (camera::render arg 1) */
+    int32_t lights_root; /* node id of `lights` (camera::render arg 2) */
+    int32_t n_nodes;
+    const rt_node *nodes;
+    int32_t n_child_index;
+    const int32_t *child_index;
+    int32_t n_spheres;
+    const rt_sphere *spheres;
+    int32_t n_quads;
+    const rt_quad *quads;
+    int32_t n_triangles;
+    const rt_triangle *triangles;
+    int32_t n_materials;
+    const rt_material *materials;
+    int32_t n_textures;
+    const rt_texture *textures;
+    int32_t n_images;
+    const rt_image *images;
+    int64_t n_image_bytes;
+    const uint8_t *image_bytes;
+    int32_t n_perlins;
+    const rt_perlin *perlins;
+} rt_scene_desc;
+
+/* Camera frame exactly as camera::initialize() derives it (camera.h:205-247). */
+typedef struct rt_camera {
+    int32_t image_width;
+    int32_t image_height;
+    int32_t sqrt_spp;  /* int(sqrt(samples_per_pixel)), camera.h:214 */
+    int32_t max_depth;
+    double center[3];
+    double pixel00_loc[3];
+    double pixel_delta_u[3];
+    double pixel_delta_v[3];
+    double defocus_disk_u[3];
+    double defocus_disk_v[3];
+    double defocus_angle;
+    double background[3];
+} rt_camera;
+
+enum rt_precision {
+    RT_PREC_F32 = 0, /* production arithmetic */
+    RT_PREC_F64 = 1  /* reference arithmetic (double, no FMA contraction): the parity path */
+};
+
+typedef struct rt_render_params {
+    uint64_t seed;      /* counter-based RNG seed; results depend on (seed,pixel,sample) only   */
+    int32_t s_begin;    /* linear stratum index range [s_begin,s_end) of sqrt_spp^2 samples:     */
+    int32_t s_end;      /*   s = s_j*sqrt_spp + s_i (camera.h:176-181); s_end<=0 means all       */
+    int32_t precision;  /* rt_precision */
+    int32_t sample_chunks; /* 0 = auto; >0 forces the number of sample chunks per pixel tile     */
+} rt_render_params;
+
+typedef struct rt_ray {
+    double orig[3];
+    double dir[3]; /* NOT normalised (ray.h:7-30) */
+    double time;
+} rt_ray; /* 56 bytes */
+
+typedef struct rt_hit {
+    int32_t prim;       /* node id of the primitive (or medium) that won, -1 = miss */
+    int32_t front_face;
+    double t;
+    double p[3];
+    double normal[3];
+    double u;
+    double v;
+} rt_hit; /* 80 bytes */
+
+typedef struct rt_stats {
+    uint64_t samples;   /* camera paths traced                                   */
+    uint64_t rays;      /* ray_color invocations that traced a ray (R x samples) */
+    double kernel_ms;   /* device time of the render kernels (hipEvent)          */
+} rt_stats;
+
+typedef struct rt_ctx rt_ctx;
+typedef struct rt_scene rt_scene;
+
+/* Create a context on HIP device `device` (one process per GPU; multi-GPU exchange is done by the
+ * caller with RCCL on the device buffers this library fills).  No reference counterpart. */
+int rt_init(int device, rt_ctx **out);
+void rt_shutdown(rt_ctx *ctx);
+const char *rt_last_error(const rt_ctx *ctx);
+
+/* Flatten + upload a scene: replaces the construction of the reference's in-memory graph
+ * (cpuRenderer.cpp:86-401 build it; bvh_node ctor bvh.h:15-41 is run by the host API before this). */
+int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out);
+void rt_scene_free(rt_scene *scene);
+
+/* Closest hit of each ray in [0.001, inf): replaces world.hit(r, interval(0.001, infinity), rec)
+ * (camera.h:300 -> hittable_list.h:24 / bvh.h:43).  `xi` (optional, one per ray) is the uniform every
+ * constant_medium on that ray consumes (constant_medium.h:41); NULL = counter-based RNG keyed by ray index.
+ * Host pointers in, host pointers out. */
+int rt_trace_batch(rt_ctx *ctx, const rt_scene *scene, const rt_ray *rays, const double *xi, size_t n,
+                   rt_hit *out, int precision);
+
+/* One frame (or one sample range of it): replaces the pixel/sample loop of camera::render
+ * (camera.h:171-186).  `d_accum` is a DEVICE pointer to image_height*image_width*3 floats that receives the
+ * UNNORMALISED per-pixel radiance sum of samples [s_begin,s_end) (overwritten, not added).
+ * `stream` is a hipStream_t (NULL = default stream).  Asynchronous when stats == NULL. */
+int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_params *params,
+                     float *d_accum, void *stream, rt_stats *stats);
+
+/* write_color (color.h:20-45) on a summed buffer: out = int(256*clamp(sqrt(scale*sum),0,0.999)), NaN -> 0.
+ * d_accum: device floats [n_pixels*3]; d_rgb8: device bytes [n_pixels*3]. */
+int rt_tonemap_device(rt_ctx *ctx, const float *d_accum, double scale, size_t n_pixels, uint8_t *d_rgb8,
+                      void *stream);
+
+/* Convenience for C/C++ callers (what the host-API camera::render uses): render all of [s_begin,s_end) on
+ * the context's device and return host buffers.  accum_rgb (optional) gets the unnormalised float sums,
+ * rgb8 (optional) the write_color bytes scaled by 1/sqrt_spp^2. */
+int rt_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_params *params,
+              float *accum_rgb, uint8_t *rgb8, rt_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

@@ -1,0 +1,86 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle.so).  Test infrastructure only -- never imported by the
+product package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from raytracing_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ROOT, "oracle", "liboracle.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+        L = C.CDLL(path)
+        L.orc_trace_batch.restype = C.c_int
+        L.orc_trace_batch.argtypes = [C.POINTER(abi.SceneDesc), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                      C.c_void_p]
+        L.orc_render.restype = C.c_int
+        L.orc_render.argtypes = [C.POINTER(abi.SceneDesc), C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_void_p]
+        L.orc_write_color.restype = None
+        L.orc_write_color.argtypes = [C.c_void_p, C.c_double, C.c_size_t, C.c_void_p]
+        L.orc_philox4x32_10.restype = None
+        L.orc_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+_libc = C.CDLL(None)
+
+
+def srand(seed: int) -> None:
+    _libc.srand(C.c_uint(seed))
+
+
+def trace_batch(scene: abi.Scene, rays: np.ndarray, xi: np.ndarray | None):
+    rays = np.ascontiguousarray(rays, dtype=abi.ray_dtype)
+    n = rays.shape[0]
+    out = np.zeros(n, dtype=abi.hit_dtype)
+    counters = np.zeros(5, dtype=np.uint64)
+    d = scene.desc()
+    xi_p = None
+    if xi is not None:
+        xi = np.ascontiguousarray(xi, dtype=np.float64)
+        xi_p = xi.ctypes.data
+    rc = lib().orc_trace_batch(C.byref(d), rays.ctypes.data, xi_p, n, out.ctypes.data, counters.ctypes.data)
+    assert rc == 0
+    return out, counters
+
+
+def render(scene: abi.Scene, camera: np.ndarray, seed: int = 0, s_begin: int = 0, s_end: int = 0, rng_mode: int = 1,
+           threads: int = 1):
+    """Returns (accum[H,W,3] float64 unscaled sums, counters[6] = aabb,sphere,quad,tri,rays,samples)."""
+    cam = np.ascontiguousarray(camera, dtype=abi.camera_dtype).reshape(1)
+    W, H = int(cam["image_width"][0]), int(cam["image_height"][0])
+    accum = np.zeros((H, W, 3), dtype=np.float64)
+    counters = np.zeros(6, dtype=np.uint64)
+    d = scene.desc()
+    rc = lib().orc_render(C.byref(d), cam.ctypes.data, seed, s_begin, s_end, rng_mode, threads, accum.ctypes.data,
+                          counters.ctypes.data)
+    assert rc == 0
+    return accum, counters
+
+
+def write_color(accum: np.ndarray, scale: float) -> np.ndarray:
+    a = np.ascontiguousarray(accum, dtype=np.float64)
+    out = np.zeros(a.shape, dtype=np.int32)
+    lib().orc_write_color(a.ctypes.data, scale, a.size // 3, out.ctypes.data)
+    return out
+
+
+def philox(ctr, key) -> np.ndarray:
+    c = np.asarray(ctr, dtype=np.uint32)
+    k = np.asarray(key, dtype=np.uint32)
+    o = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox4x32_10(c.ctypes.data, k.ctypes.data, o.ctypes.data)
+    return o
