@@ -217,10 +217,15 @@ int rt_init(int device, rt_ctx **out);
 void rt_shutdown(rt_ctx *ctx);
 const char *rt_last_error(const rt_ctx *ctx);
 
+/* Layout self-check for bindings: sizeof() of the named struct of this header ("rt_node", ...), -1 if unknown. */
+int rt_abi_sizeof(const char *name);
+
 /* Flatten + upload a scene: replaces the construction of the reference's in-memory graph
  * (cpuRenderer.cpp:86-401 build it; bvh_node ctor bvh.h:15-41 is run by the host API before this). */
 int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out);
 void rt_scene_free(rt_scene *scene);
+/* out[4] = { threaded device nodes, lights, f32 device bytes, f64 device bytes }. */
+int rt_scene_info(const rt_scene *scene, int32_t *out);
 
 /* Closest hit of each ray in [0.001, inf): replaces world.hit(r, interval(0.001, infinity), rec)
  * (camera.h:300 -> hittable_list.h:24 / bvh.h:43).  `xi` (optional, one per ray) is the uniform every

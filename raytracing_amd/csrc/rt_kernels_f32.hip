@@ -1,0 +1,44 @@
+// Production precision (float) instantiation of the path-tracing kernels + the precision-independent kernels.
+#include "rt_launch_impl.h"
+
+namespace rtamd {
+
+// Sum the per-chunk partial buffers (fixed order -> run-to-run deterministic) into the caller's accumulation buffer.
+__global__ void reduce_chunks_kernel(const float *__restrict__ partial, float *__restrict__ out, size_t n, int n_chunks) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double s = 0;
+    for (int c = 0; c < n_chunks; c++) s += (double)partial[(size_t)c * n + k];
+    out[k] = (float)s;
+}
+
+// write_color (color.h:20-45) on scale * sum.
+__global__ void tonemap_kernel(const float *__restrict__ accum, double scale, size_t n, uint8_t *__restrict__ rgb) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double x = scale * (double)accum[k];
+    if (x != x) x = 0.0;
+    x = (x > 0) ? sqrt(x) : 0.0;
+    if (x < 0.000) x = 0.000;
+    if (x > 0.999) x = 0.999;
+    rgb[k] = (uint8_t)int(256 * x);
+}
+
+template hipError_t launch_render<float>(const SceneT<float> &, const CameraT<float> &, const RenderLaunch &, float *,
+                                         unsigned long long *, hipStream_t);
+template hipError_t launch_trace<float>(const SceneT<float> &, const rt_ray *, const double *, size_t, rt_hit *, uint32_t,
+                                        uint32_t, hipStream_t);
+
+hipError_t launch_reduce_chunks(const float *partial, float *out, size_t n, int n_chunks, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, out, n, n_chunks);
+    return hipGetLastError();
+}
+
+hipError_t launch_tonemap(const float *accum, double scale, size_t n, uint8_t *rgb, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(tonemap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, accum, scale, n, rgb);
+    return hipGetLastError();
+}
+
+} // namespace rtamd

@@ -1,0 +1,162 @@
+"""ctypes binding of raytracing_amd/librt_amd.so (the C ABI of include/rt_amd.h).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is present, loading / rt_init raises.
+torch is used by callers only for device buffers, streams and torch.distributed; this module itself needs numpy only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+
+EXPORTS = ["rt_abi_sizeof", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_upload", "rt_scene_free",
+           "rt_scene_info", "rt_trace_batch", "rt_render_device", "rt_tonemap_device", "rt_render"]
+
+_lib = None
+
+
+class RtError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (raises if it has not been built: run `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtError(f"{LIB_PATH} not found: the HIP extension is not built (make -C raytracing_amd/csrc)")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.rt_abi_sizeof.restype = C.c_int
+    L.rt_abi_sizeof.argtypes = [C.c_char_p]
+    L.rt_init.restype = C.c_int
+    L.rt_init.argtypes = [C.c_int, C.POINTER(vp)]
+    L.rt_shutdown.restype = None
+    L.rt_shutdown.argtypes = [vp]
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_last_error.argtypes = [vp]
+    L.rt_scene_upload.restype = C.c_int
+    L.rt_scene_upload.argtypes = [vp, C.POINTER(abi.SceneDesc), C.POINTER(vp)]
+    L.rt_scene_free.restype = None
+    L.rt_scene_free.argtypes = [vp]
+    L.rt_scene_info.restype = C.c_int
+    L.rt_scene_info.argtypes = [vp, vp]
+    L.rt_trace_batch.restype = C.c_int
+    L.rt_trace_batch.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, C.c_int]
+    L.rt_render_device.restype = C.c_int
+    L.rt_render_device.argtypes = [vp, vp, vp, C.POINTER(abi.RenderParams), vp, vp, C.POINTER(abi.Stats)]
+    L.rt_tonemap_device.restype = C.c_int
+    L.rt_tonemap_device.argtypes = [vp, vp, C.c_double, C.c_size_t, vp, vp]
+    L.rt_render.restype = C.c_int
+    L.rt_render.argtypes = [vp, vp, vp, C.POINTER(abi.RenderParams), vp, vp, C.POINTER(abi.Stats)]
+    _lib = L
+    return L
+
+
+class Context:
+    """rt_ctx on one HIP device."""
+
+    def __init__(self, device: int = 0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.rt_init(device, C.byref(h))
+        if rc != abi.RT_OK:
+            raise RtError(f"rt_init(device={device}) failed with status {rc} (is a HIP GPU visible?)")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rt_shutdown(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int, what: str):
+        if rc != abi.RT_OK:
+            msg = self.L.rt_last_error(self.h)
+            raise RtError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")
+
+    def upload(self, scene: abi.Scene) -> "DeviceScene":
+        return DeviceScene(self, scene)
+
+
+class DeviceScene:
+    def __init__(self, ctx: Context, scene: abi.Scene):
+        self.ctx = ctx
+        self.host = scene
+        d = scene.desc()
+        h = C.c_void_p()
+        rc = ctx.L.rt_scene_upload(ctx.h, C.byref(d), C.byref(h))
+        ctx.check(rc, "rt_scene_upload")
+        self.h = h
+
+    def info(self) -> dict:
+        out = np.zeros(4, dtype=np.int32)
+        self.ctx.check(self.ctx.L.rt_scene_info(self.h, out.ctypes.data), "rt_scene_info")
+        return {"flat_nodes": int(out[0]), "lights": int(out[1]), "f32_bytes": int(out[2]), "f64_bytes": int(out[3])}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.rt_scene_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def trace_batch(self, rays: np.ndarray, xi: np.ndarray | None, precision: int = abi.RT_PREC_F64) -> np.ndarray:
+        rays = np.ascontiguousarray(rays, dtype=abi.ray_dtype)
+        n = rays.shape[0]
+        out = np.zeros(n, dtype=abi.hit_dtype)
+        xi_p = None
+        if xi is not None:
+            xi = np.ascontiguousarray(xi, dtype=np.float64)
+            assert xi.shape[0] == n
+            xi_p = xi.ctypes.data
+        rc = self.ctx.L.rt_trace_batch(self.ctx.h, self.h, rays.ctypes.data if n else None, xi_p, n,
+                                       out.ctypes.data if n else None, precision)
+        self.ctx.check(rc, "rt_trace_batch")
+        return out
+
+    def render(self, camera: np.ndarray, seed: int = 0, s_begin: int = 0, s_end: int = 0,
+               precision: int = abi.RT_PREC_F32, sample_chunks: int = 0, want_rgb8: bool = True):
+        """Host-buffer render through rt_render: returns (accum[H,W,3] float32 sums, rgb8[H,W,3] or None, stats)."""
+        cam = np.ascontiguousarray(camera, dtype=abi.camera_dtype).reshape(1)
+        W, H = int(cam["image_width"][0]), int(cam["image_height"][0])
+        accum = np.zeros((H, W, 3), dtype=np.float32)
+        rgb = np.zeros((H, W, 3), dtype=np.uint8) if want_rgb8 else None
+        p = abi.RenderParams(seed, s_begin, s_end, precision, sample_chunks)
+        st = abi.Stats()
+        rc = self.ctx.L.rt_render(self.ctx.h, self.h, cam.ctypes.data, C.byref(p), accum.ctypes.data,
+                                  rgb.ctypes.data if want_rgb8 else None, C.byref(st))
+        self.ctx.check(rc, "rt_render")
+        return accum, rgb, {"samples": st.samples, "rays": st.rays, "kernel_ms": st.kernel_ms}
+
+    def render_device(self, camera: np.ndarray, d_accum_ptr: int, seed: int = 0, s_begin: int = 0, s_end: int = 0,
+                      precision: int = abi.RT_PREC_F32, sample_chunks: int = 0, stream: int = 0, want_stats: bool = False):
+        """Device-buffer render through rt_render_device (d_accum_ptr: device address of H*W*3 floats)."""
+        cam = np.ascontiguousarray(camera, dtype=abi.camera_dtype).reshape(1)
+        p = abi.RenderParams(seed, s_begin, s_end, precision, sample_chunks)
+        st = abi.Stats()
+        rc = self.ctx.L.rt_render_device(self.ctx.h, self.h, cam.ctypes.data, C.byref(p), d_accum_ptr, stream or None,
+                                         C.byref(st) if want_stats else None)
+        self.ctx.check(rc, "rt_render_device")
+        return {"samples": st.samples, "rays": st.rays, "kernel_ms": st.kernel_ms} if want_stats else None
+
+    def tonemap_device(self, d_accum_ptr: int, scale: float, n_pixels: int, d_rgb_ptr: int, stream: int = 0):
+        rc = self.ctx.L.rt_tonemap_device(self.ctx.h, d_accum_ptr, scale, n_pixels, d_rgb_ptr, stream or None)
+        self.ctx.check(rc, "rt_tonemap_device")

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/*.npz from the compiled reference (oracle/_ref/refgen).
+
+Runs only where /root/reference exists (this container).  The fixtures are DATA produced by running the
+reference's own code (scene graphs, hit records, rendered pixel sums); no reference source is stored.
+
+  scene{N}.npz   reference scene N (1 first_scene, 2 cornell_box, 3 final_scene, 4 mesh_scene), use_bvh=true, flat
+                 format of include/rt_amd.h, camera frame for 64x36 / spp 9 / depth 10
+  trace{N}.npz   64x36 pixel-centre rays + 2000 secondary-like rays: rays, injected medium uniform, reference hit records
+                 (prim = node id, t, p, normal, u, v, front_face), all from world.hit() of the reference
+  img{N}.npz     32x18, spp 9, depth 12 frame rendered by the reference single-threaded from srand(7): per-pixel double
+                 sums and write_color ints (cross-checked in refgen against camera::render()'s PPM), + camera frame
+  conv{N}.npz    48x27, depth 50 converged frame: mean of 5 independent reference runs x 16900 spp (srand 11..15)
+                 -- optional, produced with --converged (about 25 core-minutes)
+"""
+import argparse
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from raytracing_amd import abi  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+WORK = os.path.join(REF, "work")
+OUT = os.path.join(REF, "out")
+GOLD = os.path.dirname(os.path.abspath(__file__))
+ENV = dict(os.environ, RTW_IMAGES="/root/reference/images/resource")
+
+
+def refgen(*args):
+    subprocess.run([os.path.join(REF, "refgen"), *map(str, args)], cwd=WORK, env=ENV, check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+def read_trace(path):
+    b = open(path, "rb").read()
+    assert b[:8] == b"RTTRACE1"
+    n = int(np.frombuffer(b, "<i8", 1, 8)[0])
+    off = 16
+    rays = np.frombuffer(b, abi.ray_dtype, n, off).copy()
+    off += n * abi.ray_dtype.itemsize
+    xi = np.frombuffer(b, "<f8", n, off).copy()
+    off += n * 8
+    hits = np.frombuffer(b, abi.hit_dtype, n, off).copy()
+    return rays, xi, hits
+
+
+def read_img(path):
+    b = open(path, "rb").read()
+    assert b[:8] == b"RTIMG001"
+    W, H, n, d = (int(x) for x in np.frombuffer(b, "<i4", 4, 8))
+    seed = int(np.frombuffer(b, "<u4", 1, 24)[0])
+    off = 28
+    sums = np.frombuffer(b, "<f8", W * H * 3, off).reshape(H, W, 3).copy()
+    off += W * H * 3 * 8
+    by = np.frombuffer(b, "<i4", W * H * 3, off).reshape(H, W, 3).copy()
+    return W, H, n, d, seed, sums, by
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--converged", action="store_true", help="also (re)run the long converged renders")
+    ap.add_argument("--scenes", default="1,2,3,4")
+    a = ap.parse_args()
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
+    os.makedirs(OUT, exist_ok=True)
+    for s in (int(x) for x in a.scenes.split(",")):
+        refgen("dump", s, 64, 36, 9, 10, 1, f"{OUT}/scene{s}.rtscene")
+        sc = abi.Scene.load(f"{OUT}/scene{s}.rtscene")
+        sc.save_npz(f"{GOLD}/scene{s}.npz")
+        refgen("trace", s, 64, 36, 9, 10, 1, f"{OUT}/trace{s}.bin", 2000)
+        rays, xi, hits = read_trace(f"{OUT}/trace{s}.bin")
+        np.savez_compressed(f"{GOLD}/trace{s}.npz", rays=rays.view("u1"), xi=xi, hits=hits.view("u1"))
+        refgen("dump", s, 32, 18, 9, 12, 1, f"{OUT}/scene{s}_32.rtscene")
+        cam = abi.Scene.load(f"{OUT}/scene{s}_32.rtscene").camera
+        refgen("render", s, 32, 18, 9, 12, 1, f"{OUT}/img{s}.bin", 7)
+        W, H, n, d, seed, sums, by = read_img(f"{OUT}/img{s}.bin")
+        np.savez_compressed(f"{GOLD}/img{s}.npz", camera=cam.view("u1"), seed=np.array([seed]), sums=sums, bytes=by)
+        print(f"scene {s}: {len(sc.nodes)} nodes, {len(rays)} traced rays, {W}x{H} frame")
+        seeds = (11, 12, 13, 14, 15)
+        if a.converged:
+            procs = [subprocess.Popen([os.path.join(REF, "refgen"), "render_nocheck", str(s), "48", "27", "16900", "50",
+                                       "1", f"{OUT}/conv_{s}_{k}.bin", str(k)], cwd=WORK, env=ENV,
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for k in seeds]
+            for p in procs:
+                assert p.wait() == 0
+        if all(os.path.exists(f"{OUT}/conv_{s}_{k}.bin") for k in seeds):
+            refgen("dump", s, 48, 27, 16900, 50, 1, f"{OUT}/scene{s}_48.rtscene")
+            cam = abi.Scene.load(f"{OUT}/scene{s}_48.rtscene").camera
+            tot, spp = None, 0
+            runs = []
+            for k in seeds:
+                W, H, n, d, seed, sums, by = read_img(f"{OUT}/conv_{s}_{k}.bin")
+                runs.append(sums / (n * n))
+                tot = sums if tot is None else tot + sums
+                spp += n * n
+            np.savez_compressed(f"{GOLD}/conv{s}.npz", camera=cam.view("u1"), mean=(tot / spp).astype(np.float64),
+                                spp=np.array([spp]), runs=np.stack(runs).astype(np.float32))
+            print(f"scene {s}: converged fixture from {spp} spp")
+
+
+if __name__ == "__main__":
+    main()
