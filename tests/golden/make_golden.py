@@ -10,7 +10,8 @@ reference's own code (scene graphs, hit records, rendered pixel sums); no refere
                  (prim = node id, t, p, normal, u, v, front_face), all from world.hit() of the reference
   img{N}.npz     32x18, spp 9, depth 12 frame rendered by the reference single-threaded from srand(7): per-pixel double
                  sums and write_color ints (cross-checked in refgen against camera::render()'s PPM), + camera frame
-  conv{N}.npz    48x27, depth 50 converged frame: mean of 5 independent reference runs x 16900 spp (srand 11..15)
+  conv{N}.npz    48x27, depth 50 converged frame: mean of 5 (final_scene: 25) independent reference runs x 16900 spp
+                 (srand 11..15 / 11..35); `runs` keeps the first five for the noise-floor estimate
                  -- optional, produced with --converged (about 25 core-minutes)
 """
 import argparse
@@ -81,7 +82,7 @@ def main():
         W, H, n, d, seed, sums, by = read_img(f"{OUT}/img{s}.bin")
         np.savez_compressed(f"{GOLD}/img{s}.npz", camera=cam.view("u1"), seed=np.array([seed]), sums=sums, bytes=by)
         print(f"scene {s}: {len(sc.nodes)} nodes, {len(rays)} traced rays, {W}x{H} frame")
-        seeds = (11, 12, 13, 14, 15)
+        seeds = tuple(range(11, 36)) if s == 3 else (11, 12, 13, 14, 15)  # final_scene is ~16 dB noisier: 25 runs
         if a.converged:
             procs = [subprocess.Popen([os.path.join(REF, "refgen"), "render_nocheck", str(s), "48", "27", "16900", "50",
                                        "1", f"{OUT}/conv_{s}_{k}.bin", str(k)], cwd=WORK, env=ENV,
@@ -99,7 +100,7 @@ def main():
                 tot = sums if tot is None else tot + sums
                 spp += n * n
             np.savez_compressed(f"{GOLD}/conv{s}.npz", camera=cam.view("u1"), mean=(tot / spp).astype(np.float64),
-                                spp=np.array([spp]), runs=np.stack(runs).astype(np.float32))
+                                spp=np.array([spp]), runs=np.stack(runs[:5]).astype(np.float32))
             print(f"scene {s}: converged fixture from {spp} spp")
 
 
