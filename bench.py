@@ -20,6 +20,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from raytracing_amd import abi, camera, lib, scenes  # noqa: E402
+from raytracing_amd.distributed import reduce_accum, split_range  # noqa: E402
 
 # Work of the reference algorithm per camera sample on final_scene (BASELINE.md / SURVEY.md 8d; re-measured by the
 # oracle's counters in tests/test_work_counts.py): flops = 27*A + 30*S + 55*Q + 52*T + 120*R
@@ -27,20 +28,16 @@ FLOPS_PER_SAMPLE = {"final_scene": 27 * 102.5 + 30 * 22.1 + 55 * 29.2 + 52 * 0 +
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (vector), packed FMA
 
 
-def split_range(n, world, rank):
-    return (rank * n) // world, ((rank + 1) * n) // world
-
-
 def cpu_baseline(scene, cores):
     """The oracle (CPU restatement of the reference algorithm, same Philox streams) on a bounded sample of the workload."""
     from tests import oracle_lib as O
-    W, H, spp = 480, 270, 16
+    W, H, spp = 480, 270, 64
     cam = camera.scene_camera(3, W, H, spp, 50)
     t0 = time.time()
     _, cnt = O.render(scene, cam, seed=1, rng_mode=1, threads=cores)
     dt = time.time() - t0
     return {"value": round(W * H * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"final_scene {W}x{H}, 16 spp, depth 50 ({W * H * spp} samples, {dt:.1f} s wall)"}
+            "sample": f"final_scene {W}x{H}, {spp} spp, depth 50 ({W * H * spp} samples, {dt:.1f} s wall)"}
 
 
 def main():
@@ -81,8 +78,7 @@ def main():
         ds.render_device(cam, accum.data_ptr(), seed=1984, s_begin=s0, s_end=s1, precision=abi.RT_PREC_F32, stream=stream)
         if k is not None:
             ev[k][1].record()
-        if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        reduce_accum(accum, dst=0)
         if rank == 0:
             ds.tonemap_device(accum.data_ptr(), 1.0 / (n * n), H * W, rgb.data_ptr(), stream=stream)
 

@@ -1,0 +1,85 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol include/rt_amd.h declares; struct layouts of
+the Python mirror match the compiled ones; host-side argument checks that need no device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from raytracing_amd import abi, camera, distributed, lib
+from tests import fixtures as fx
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    L = lib.load()
+    names = declared_functions()
+    assert len(names) >= 11
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/rt_amd.h but not exported"
+    assert set(lib.EXPORTS) == set(names)
+
+
+def test_struct_layouts_match_compiled_library():
+    abi.check_layout()
+    L = lib.load()
+    for name, (_, size) in abi.EXPECTED_SIZES.items():
+        assert L.rt_abi_sizeof(name.encode()) == size, name
+    assert L.rt_abi_sizeof(b"rt_scene_desc") == C.sizeof(abi.SceneDesc)
+    assert L.rt_abi_sizeof(b"rt_render_params") == C.sizeof(abi.RenderParams)
+    assert L.rt_abi_sizeof(b"rt_stats") == C.sizeof(abi.Stats)
+    assert L.rt_abi_sizeof(b"nope") == -1
+
+
+def test_no_cpu_fallback():
+    """Without a GPU rt_init must fail loudly (the product never routes through the oracle or any CPU path)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(lib.RtError):
+        lib.Context(0)
+
+
+def test_product_does_not_reference_oracle():
+    for base in ("raytracing_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".py", ".h", ".hpp", ".cpp", ".hip", "Makefile")):
+                    text = open(os.path.join(dp, fn), errors="ignore").read()
+                    assert "liboracle" not in text and "oracle_lib" not in text, (dp, fn)
+                    assert not re.search(r"#include[^\n]*oracle|import[^\n]*oracle|from[^\n]*oracle[^\n]*import", text), (dp, fn)
+
+
+def test_scene_npz_roundtrip(tmp_path):
+    sc = fx.scene(2)
+    p = str(tmp_path / "s.npz")
+    sc.save_npz(p)
+    assert abi.Scene.load(p).equal(sc)
+    d = sc.desc()
+    assert d.n_nodes == len(sc.nodes) and d.n_quads == 13 and d.n_spheres == 2
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4])
+def test_python_camera_matches_reference_frame(n):
+    assert camera.scene_camera(n, 64, 36, 9, 10).tobytes() == fx.scene(n).camera.tobytes()
+    cam32, _, _, _ = fx.img(n)
+    assert camera.scene_camera(n, 32, 18, 9, 12).tobytes() == cam32.tobytes()
+
+
+def test_split_range_properties():
+    for n in (1, 9, 961, 484):
+        for world in (1, 2, 3, 4, 8):
+            parts = [distributed.split_range(n, world, r) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+    assert sorted(sum((distributed.frame_shards(124, 8, r) for r in range(8)), [])) == list(range(124))

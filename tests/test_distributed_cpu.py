@@ -1,0 +1,43 @@
+"""CPU, world_size 2 over gloo: the spp-range split + reduce used by bench.py gives the single-process frame.
+(The renderer stand-in on CPU ranks is the oracle, which shares the HIP kernels' RNG stream protocol.)"""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from raytracing_amd.distributed import reduce_accum, split_range
+from tests import fixtures as fx
+from tests import oracle_lib as O
+
+
+def _worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = fx.scene(2)
+    cam, _, _, _ = fx.img(2)
+    n = int(cam["sqrt_spp"][0])
+    s0, s1 = split_range(n * n, world, rank)
+    acc, _ = O.render(sc, cam, seed=11, s_begin=s0, s_end=s1, rng_mode=1)
+    t = torch.from_numpy(acc.astype(np.float32).reshape(-1))
+    reduce_accum(t, dst=0)
+    if rank == 0:
+        np.save(out_path, t.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_spp_split_matches_single(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "sum.npy")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    sc = fx.scene(2)
+    cam, _, _, _ = fx.img(2)
+    whole, _ = O.render(sc, cam, seed=11, rng_mode=1)
+    np.testing.assert_allclose(got, whole.reshape(-1), rtol=1e-5, atol=1e-6)
