@@ -61,8 +61,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    scene = scenes.load("final_scene")
-    cam = camera.scene_camera(3, a.width, a.height, a.spp, a.depth)
+    scene = scenes.build("final_scene", a.width, a.height, a.spp, a.depth)  # C++ scene API: BVH built on the host
+    cam = scene.camera
     W, H, n = int(cam["image_width"][0]), int(cam["image_height"][0]), int(cam["sqrt_spp"][0])
     ctx = lib.Context(local_rank)
     ds = ctx.upload(scene)

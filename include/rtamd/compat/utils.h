@@ -1,0 +1,2 @@
+// Forwarding header: lets reference-style `#include "utils.h"` resolve to the MI355X scene API.
+#include "../scene_api.h"

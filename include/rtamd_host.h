@@ -1,0 +1,34 @@
+/*
+ * rtamd_host.h -- C entry points of the host-side library (raytracing_amd/librtamd_host.so): the reference's five
+ * scenes written against the scene API of include/rtamd/scene_api.h, handed out as flat scene descriptions.
+ * Used by bench.py / tests (ctypes) and by the rtamd_render command-line driver.  No GPU is needed for these calls.
+ *
+ * Reference counterparts: first_scene / cornell_box / final_scene / mesh_scene / first_scene_moving
+ * (src/cpu/cpuRenderer.cpp:19-401) up to, but not including, their renderer.render(world, lights) call.
+ */
+#ifndef RTAMD_HOST_H
+#define RTAMD_HOST_H
+#include "rt_amd.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtamd_host_scene rtamd_host_scene;
+
+/* scene: 1 first_scene, 2 cornell_box, 3 final_scene, 4 mesh_scene, 5 first_scene_moving(frame) -- the numbering of
+ * cpuRenderer.cpp:453-458.  std::rand is re-seeded with srand(1) first, so every call builds what a fresh reference
+ * process builds.  asset_dir must hold earthmap.jpg.rtwtex and shapes/small_bunny.obj (raytracing_amd/assets).
+ * Returns NULL on bad arguments. */
+rtamd_host_scene *rtamd_host_build_scene(int scene, int image_width, int image_height, int samples_per_pixel,
+                                         int max_depth, int use_bvh, int frame, const char *asset_dir);
+const rt_scene_desc *rtamd_host_scene_desc(const rtamd_host_scene *s);
+/* camera::initialize()'s frame for the scene's camera (camera.h:205-247) */
+int rtamd_host_scene_camera(const rtamd_host_scene *s, rt_camera *out);
+/* write the "RTSCENE1" container (scene + camera) */
+int rtamd_host_scene_save(const rtamd_host_scene *s, const char *path);
+void rtamd_host_scene_free(rtamd_host_scene *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

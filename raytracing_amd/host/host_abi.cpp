@@ -1,0 +1,50 @@
+// host_abi.cpp -- C entry points of librtamd_host.so (include/rtamd_host.h).
+#include "../../include/rtamd_host.h"
+
+#include "scenes.h"
+
+struct rtamd_host_scene {
+    rtamd::BuiltScene built;
+    rtamd::FlatScene flat;
+    rt_scene_desc desc{};
+    rt_camera cam{};
+};
+
+extern "C" {
+
+rtamd_host_scene *rtamd_host_build_scene(int scene, int image_width, int image_height, int samples_per_pixel,
+                                         int max_depth, int use_bvh, int frame, const char *asset_dir) {
+    if (image_width <= 0 || image_height <= 0 || samples_per_pixel <= 0 || max_depth < 0) return nullptr;
+    auto *s = new rtamd_host_scene;
+    std::srand(1); // a fresh reference process starts from the default seed
+    if (!rtamd::build_scene(scene, use_bvh != 0, frame, asset_dir ? asset_dir : "", s->built)) {
+        delete s;
+        return nullptr;
+    }
+    camera &c = s->built.cam;
+    c.image_width = image_width;
+    c.aspect_ratio = double(image_width) / double(image_height); // cpuRenderer.cpp:437
+    c.samples_per_pixel = samples_per_pixel;
+    c.max_depth = max_depth;
+    s->cam = c.frame();
+    camera::flatten(s->built.world, s->built.lights, s->flat);
+    s->desc = s->flat.desc();
+    return s;
+}
+
+const rt_scene_desc *rtamd_host_scene_desc(const rtamd_host_scene *s) { return s ? &s->desc : nullptr; }
+
+int rtamd_host_scene_camera(const rtamd_host_scene *s, rt_camera *out) {
+    if (!s || !out) return RT_ERR_INVALID;
+    *out = s->cam;
+    return RT_OK;
+}
+
+int rtamd_host_scene_save(const rtamd_host_scene *s, const char *path) {
+    if (!s || !path) return RT_ERR_INVALID;
+    return s->flat.save(path, &s->cam) ? RT_OK : RT_ERR_INVALID;
+}
+
+void rtamd_host_scene_free(rtamd_host_scene *s) { delete s; }
+
+} // extern "C"

@@ -1,18 +1,12 @@
-"""Access to the reference's scenes as flat scene descriptions.
-
-`load(name)` returns the scene serialised from the reference's own scene function (tests/golden/scene*.npz, produced by
-oracle/refgen.cpp); the C++ host API (raytracing_amd/host) builds the same descriptions from scene code written against
-the reference's scene API."""
+"""The reference's scenes as flat scene descriptions, built by the C++ host library (raytracing_amd/host)."""
 from __future__ import annotations
 
-import os
+from . import abi, host
 
-from . import abi
-
-_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SCENE_IDS = {"first_scene": 1, "cornell_box": 2, "final_scene": 3, "mesh_scene": 4}
+SCENE_IDS = {"first_scene": 1, "cornell_box": 2, "final_scene": 3, "mesh_scene": 4, "first_scene_moving": 5}
 
 
-def load(name: str) -> abi.Scene:
-    n = SCENE_IDS[name]
-    return abi.Scene.load(os.path.join(_ROOT, "tests", "golden", f"scene{n}.npz"))
+def build(name: str, image_width: int, image_height: int, samples_per_pixel: int, max_depth: int, use_bvh: bool = True,
+          frame: int = 0) -> abi.Scene:
+    """Scene + camera frame (scene.camera) for one of the reference's scene functions (cpuRenderer.cpp:19-401)."""
+    return host.build_scene(SCENE_IDS[name], image_width, image_height, samples_per_pixel, max_depth, use_bvh, frame)

@@ -69,6 +69,14 @@ def main():
     a = ap.parse_args()
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
     os.makedirs(OUT, exist_ok=True)
+    # extra graph shapes: one frame of the bounce animation (cpuRenderer.cpp:19) and a scene without BVH
+    refgen("dump", 5, 64, 36, 9, 10, 1, f"{OUT}/scene5_f7.rtscene", 0, 7)
+    abi.Scene.load(f"{OUT}/scene5_f7.rtscene").save_npz(f"{GOLD}/scene5_f7.npz")
+    refgen("dump", 2, 64, 36, 9, 10, 0, f"{OUT}/scene2_nobvh.rtscene")
+    abi.Scene.load(f"{OUT}/scene2_nobvh.rtscene").save_npz(f"{GOLD}/scene2_nobvh.npz")
+    refgen("trace", 2, 64, 36, 9, 10, 0, f"{OUT}/trace2_nobvh.bin", 500)
+    rays, xi, hits = read_trace(f"{OUT}/trace2_nobvh.bin")
+    np.savez_compressed(f"{GOLD}/trace2_nobvh.npz", rays=rays.view("u1"), xi=xi, hits=hits.view("u1"))
     for s in (int(x) for x in a.scenes.split(",")):
         refgen("dump", s, 64, 36, 9, 10, 1, f"{OUT}/scene{s}.rtscene")
         sc = abi.Scene.load(f"{OUT}/scene{s}.rtscene")

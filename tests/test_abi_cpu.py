@@ -13,10 +13,19 @@ from tests import fixtures as fx
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
+def declared_functions(header="rt_amd.h", prefix="rt_"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text)))
+
+
+def test_host_header_symbols_are_exported():
+    from raytracing_amd import host
+    L = host.load()
+    names = declared_functions("rtamd_host.h", "rtamd_host_")
+    assert set(names) == set(host.EXPORTS)
+    for n in names:
+        assert hasattr(L, n)
 
 
 def test_header_symbols_are_exported():

@@ -147,15 +147,16 @@ def test_bad_arguments_return_status(gpu_ctx, scenes):
 @pytest.mark.parametrize("n", [2, 3, 4, 1])
 def test_converged_frame_psnr_vs_reference(scenes, n):
     """PSNR >= 40 dB (8-bit display space) of a converged f32 GPU frame against the converged frame of the compiled
-    reference (mean of 5 independent runs, 84.5k spp).  The reference's own run-to-run noise floor at that sample count is
+    reference (mean of 5 independent runs = 84.5k spp; final_scene 25 runs = 422.5k spp).  The reference's own run-to-run noise floor at that sample count is
     measured from the fixture and printed next to it."""
     c = fx.conv(n)
     if c is None:
         pytest.skip("converged fixture not generated")
     cam, mean, spp, runs = c
-    cam = fx.with_size(cam, sqrt_spp=300)  # 90k spp
+    k = 1000 if n == 3 else 300  # final_scene is ~16 dB noisier than the others: 10^6 spp against the 422.5k-spp reference
+    cam = fx.with_size(cam, sqrt_spp=k)
     acc, _, st = scenes[n].render(cam, seed=2024, precision=abi.RT_PREC_F32)
-    img_gpu = O.write_color(acc.astype(np.float64), 1.0 / 90000)
+    img_gpu = O.write_color(acc.astype(np.float64), 1.0 / (k * k))
     img_ref = O.write_color(mean, 1.0)
     psnr = fx.psnr8(img_gpu, img_ref)
     half_a = O.write_color(runs[:2].mean(axis=0).astype(np.float64), 1.0)
