@@ -345,7 +345,9 @@ template <class R> struct Hit { // hittable.h:10 hit_record
 };
 
 template <class R> RT_DEV void sphere_uv(V3<R> p, R &u, R &v) { // sphere.h:89
-    R theta = m_acos(-p.y);
+    R ny = -p.y;
+    if constexpr (sizeof(R) == 4) ny = m_max(R(-1), m_min(R(1), ny)); // (p-c)/r can exceed 1 by an ulp in float
+    R theta = m_acos(ny);
     R phi = m_atan2(-p.z, p.x) + Const<R>::pi;
     u = phi / (R(2) * Const<R>::pi);
     v = theta / Const<R>::pi;
@@ -520,13 +522,23 @@ template <class R> RT_DEV V3<R> random_cosine_direction(Rng<R> &g) { // vec3.h:1
     return mk<R>(m_cos(phi) * sr, m_sin(phi) * sr, m_sqrt(R(1) - r2));
 }
 
-template <class R> RT_DEV R light_pdf_one(const LightT<R> &L, V3<R> origin, V3<R> dir) {
+// `generated` = this light produced `dir` (light_random picked it), so in exact arithmetic the direction hits it.  In
+// float the containment test of a direction drawn on the rim of the sphere's cone / the quad's edge can fail by
+// rounding, which would make the mixture pdf 0 and the sample 0/0; the float path therefore skips the test for the
+// generating light.  The double path always runs the reference's test.
+template <class R> RT_DEV R light_pdf_one(const LightT<R> &L, V3<R> origin, V3<R> dir, bool generated) {
     RayT<R> r{origin, dir, R(0)}; // 2-argument ray ctor: time 0 (ray.h:14)
-    if (L.kind == LIGHT_SPHERE) {  // sphere.h:62
+    const bool skip_test = (sizeof(R) == 4) && generated;
+    if (L.kind == LIGHT_SPHERE) { // sphere.h:62
         R t;
-        if (!sphere_t(L.s, r, R(0.001), Const<R>::inf, t)) return R(0);
+        if (!skip_test && !sphere_t(L.s, r, R(0.001), Const<R>::inf, t)) return R(0);
         R dist_squared = len2(ld3(L.s.c) - origin);
         R x = L.s.radius * L.s.radius / dist_squared;
+        if constexpr (sizeof(R) == 4) {
+            // an origin ON the sphere (the floor point a sphere rests on) lands a few ulp inside it in float: x = 1 + eps
+            // would give sqrt(<0).  Genuinely interior origins (x well above 1) keep the reference's NaN (sphere.h:70).
+            if (x > R(1) && x < R(1.0001)) x = R(1);
+        }
         R cos_theta_max = m_sqrt(R(1) - x);
         R one_minus_cos = R(1) - cos_theta_max;
         if constexpr (sizeof(R) == 4) one_minus_cos = x / (R(1) + cos_theta_max); // same value, no cancellation in float
@@ -535,7 +547,15 @@ template <class R> RT_DEV R light_pdf_one(const LightT<R> &L, V3<R> origin, V3<R
     }
     if (L.kind == LIGHT_QUAD) { // quad.h:75
         R t, al, be;
-        if (!quad_t(L.q, r, R(0.001), Const<R>::inf, t, al, be)) return R(0);
+        if (skip_test) {
+            V3<R> n = ld3(L.q.n);
+            R denom = dot(n, dir);
+            if (m_abs(denom) < R(1e-8)) return R(0);
+            t = (L.q.D - dot(n, origin)) / denom;
+            if (!(t >= R(0.001))) return R(0);
+        } else {
+            if (!quad_t(L.q, r, R(0.001), Const<R>::inf, t, al, be)) return R(0);
+        }
         R distance_squared = t * t * len2(dir);
         R cosine = m_abs(dot(dir, ld3(L.q.n)) / len(dir)); // |.| makes the face flip of rec.normal irrelevant
         return distance_squared / (cosine * L.q.area);
@@ -543,16 +563,17 @@ template <class R> RT_DEV R light_pdf_one(const LightT<R> &L, V3<R> origin, V3<R
     return R(0); // hittable.h:35
 }
 
-template <class R> RT_DEV R light_pdf(const SceneT<R> &sc, V3<R> origin, V3<R> dir) {
-    if (!sc.lights_is_list) return light_pdf_one(sc.lights[0], origin, dir);
+// `picked` = index of the light that generated `dir`, or -1 when the direction came from the BRDF sampler.
+template <class R> RT_DEV R light_pdf(const SceneT<R> &sc, V3<R> origin, V3<R> dir, int picked) {
+    if (!sc.lights_is_list) return light_pdf_one(sc.lights[0], origin, dir, picked == 0);
     R weight = R(1.0) / R(sc.n_lights); // hittable_list.h:42
     R sum = R(0);
-    for (int k = 0; k < sc.n_lights; k++) sum += weight * light_pdf_one(sc.lights[k], origin, dir);
+    for (int k = 0; k < sc.n_lights; k++) sum += weight * light_pdf_one(sc.lights[k], origin, dir, picked == k);
     return sum;
 }
 
-template <class R> RT_DEV V3<R> light_random(const SceneT<R> &sc, V3<R> origin, Rng<R> &g) {
-    int pick = 0;
+template <class R> RT_DEV V3<R> light_random(const SceneT<R> &sc, V3<R> origin, Rng<R> &g, int &pick) {
+    pick = 0;
     if (sc.lights_is_list) { // hittable_list.h:52: random_int(0, n-1) = int(0 + n*xi)
         pick = int(R(0) + (R(sc.n_lights) - R(0)) * g.next());
         if (pick >= sc.n_lights) pick = sc.n_lights - 1; // f32 rounding guard (xi < 1 always in f64)
@@ -565,6 +586,9 @@ template <class R> RT_DEV V3<R> light_random(const SceneT<R> &sc, V3<R> origin, 
         R r1 = g.next();
         R r2 = g.next();
         R x = L.s.radius * L.s.radius / distance_squared;
+        if constexpr (sizeof(R) == 4) {
+            if (x > R(1) && x < R(1.0001)) x = R(1); // see light_pdf_one
+        }
         R cm = m_sqrt(R(1) - x);
         R z = R(1) + r2 * (cm - R(1));
         R phi = R(2) * Const<R>::pi * r1;
@@ -659,10 +683,11 @@ RT_DEV bool bounce(const SceneT<R> &sc, const CameraT<R> &cam, RayT<R> &ray, V3<
     const bool lambert = (m.kind == RT_MAT_LAMBERTIAN);
     V3<R> atten = tex_value(sc, m.tex, h.u, h.v, h.p);
     V3<R> dir;
-    if (g.next() < R(0.5)) dir = light_random(sc, h.p, g);
+    int picked = -1;
+    if (g.next() < R(0.5)) dir = light_random(sc, h.p, g, picked);
     else if (lambert) dir = Onb<R>(h.n).transform(random_cosine_direction(g)); // pdf.h:40
     else dir = random_unit_vector(g);                                          // pdf.h:25
-    R v0 = light_pdf(sc, h.p, dir);
+    R v0 = light_pdf(sc, h.p, dir, picked);
     R v1, spdf;
     if (lambert) {
         R cosine_theta = dot(unit(dir), unit(h.n)); // cosine_pdf::value pdf.h:35 (onb re-normalises w)
@@ -675,6 +700,12 @@ RT_DEV bool bounce(const SceneT<R> &sc, const CameraT<R> &cam, RayT<R> &ray, V3<
     }
     R pdf_value = R(0.5) * v0 + R(0.5) * v1;
     R wgt = spdf / pdf_value;
+#ifdef RT_DEBUG_NAN
+    if (wgt != wgt || atten.x != atten.x)
+        printf("NAN diffuse: bounce %d mat %d kind %d v0 %g v1 %g spdf %g dir %g %g %g n %g %g %g p %g %g %g atten %g t %g primkind %d\n", bounce_idx,
+               h.mat, m.kind, (double)v0, (double)v1, (double)spdf, (double)dir.x, (double)dir.y, (double)dir.z, (double)h.n.x,
+               (double)h.n.y, (double)h.n.z, (double)h.p.x, (double)h.p.y, (double)h.p.z, (double)atten.x, (double)h.t, h.kind);
+#endif
     beta = beta * scale<R>(wgt, atten);
     ray.o = h.p;
     ray.d = dir;
@@ -731,7 +762,15 @@ __global__ void __launch_bounds__(256) render_kernel(SceneT<R> sc, CameraT<R> ca
         bool alive = false;
         if (depth > 0) { // camera.h:294
             rays++;
+    #ifdef RT_DEBUG_NAN
+            bool was_ok = !(beta.x != beta.x) && !(ray.d.x != ray.d.x) && !(L.x != L.x);
+#endif
             alive = bounce(sc, cam, ray, beta, L, g, cam.max_depth - depth);
+#ifdef RT_DEBUG_NAN
+            if (was_ok && ((beta.x != beta.x) || (ray.d.x != ray.d.x) || (ray.o.x != ray.o.x) || (L.x != L.x)))
+                printf("NAN after bounce %d: beta %g dir %g %g %g o %g %g %g L %g alive %d\n", cam.max_depth - depth, (double)beta.x,
+                       (double)ray.d.x, (double)ray.d.y, (double)ray.d.z, (double)ray.o.x, (double)ray.o.y, (double)ray.o.z, (double)L.x, (int)alive);
+#endif
             depth--;
             if (alive && depth == 0) { // depth exhausted: the recursion returns 0 here (camera.h:294-295)
                 L = L + beta * mk<R>(R(0), R(0), R(0));
