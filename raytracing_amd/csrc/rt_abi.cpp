@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -27,12 +28,16 @@ struct rt_ctx {
     unsigned long long *counter = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cus = 256;
+    // development knobs (environment RT_AMD_LDS_UNITS / RT_AMD_LEAF_T / RT_AMD_SHADE_T); -1 / 0 = library default
+    int lds_limit_units = -1;
+    int leaf_threshold = 0, shade_threshold = 0;
 };
 
 template <class R> struct DeviceScene {
     void *blob = nullptr;
     size_t bytes = 0;
     SceneT<R> sc{};
+    int n_fused_boxes = 0;
 };
 
 struct rt_scene {
@@ -75,25 +80,21 @@ struct BlobBuilder {
 template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, DeviceScene<R> &ds) {
     Flat<R> f;
     std::string err;
-    Flattener<R> fl(*desc, f, err);
+    Flattener<R> fl(*desc, f, err, /*fuse_boxes=*/sizeof(R) == 4);
     int rc = fl.run();
     if (rc) return set_err(ctx, rc, err);
     BlobBuilder b;
-    size_t o_nodes = b.add(f.nodes), o_sph = b.add(f.spheres), o_quads = b.add(f.quads), o_tris = b.add(f.tris);
-    size_t o_media = b.add(f.media), o_xf = b.add(f.xforms), o_mats = b.add(f.mats), o_texs = b.add(f.texs);
+    size_t o_stream = b.add(f.stream), o_cold = b.add(f.cold);
+    size_t o_xf = b.add(f.xforms), o_mats = b.add(f.mats), o_texs = b.add(f.texs);
     size_t o_img = b.add(f.images), o_bytes = b.add_bytes(desc->image_bytes, (size_t)desc->n_image_bytes);
     size_t o_perlin = b.add(f.perlins), o_lights = b.add(f.lights);
-    size_t o_sid = b.add(f.sphere_ids), o_qid = b.add(f.quad_ids), o_tid = b.add(f.tri_ids);
     ds.bytes = b.host.size();
     HIP_TRY(ctx, hipMalloc(&ds.blob, ds.bytes));
     HIP_TRY(ctx, hipMemcpy(ds.blob, b.host.data(), ds.bytes, hipMemcpyHostToDevice));
     uint8_t *base = (uint8_t *)ds.blob;
     SceneT<R> &s = ds.sc;
-    s.nodes = (const NodeT<R> *)(base + o_nodes);
-    s.spheres = (const SphereT<R> *)(base + o_sph);
-    s.quads = (const QuadT<R> *)(base + o_quads);
-    s.tris = (const TriT<R> *)(base + o_tris);
-    s.media = (const MediumT<R> *)(base + o_media);
+    s.stream = (const UnitT<R> *)(base + o_stream);
+    s.cold = (const UnitT<R> *)(base + o_cold);
     s.xforms = (const XformT<R> *)(base + o_xf);
     s.mats = (const MatT<R> *)(base + o_mats);
     s.texs = (const TexT<R> *)(base + o_texs);
@@ -101,12 +102,13 @@ template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, Device
     s.image_bytes = base + o_bytes;
     s.perlins = (const PerlinT<R> *)(base + o_perlin);
     s.lights = (const LightT<R> *)(base + o_lights);
-    s.sphere_ids = (const int32_t *)(base + o_sid);
-    s.quad_ids = (const int32_t *)(base + o_qid);
-    s.tri_ids = (const int32_t *)(base + o_tid);
-    s.n_nodes = (int)f.nodes.size();
+    s.n_units = (int)f.stream.size();
+    int cap = LaunchCfg<R>::lds_bytes / (int)sizeof(UnitT<R>);
+    if (ctx->lds_limit_units >= 0 && ctx->lds_limit_units < cap) cap = ctx->lds_limit_units;
+    s.lds_units = s.n_units < cap ? s.n_units : cap;
     s.n_lights = (int)f.lights.size();
     s.lights_is_list = f.lights_is_list;
+    ds.n_fused_boxes = f.n_fused_boxes;
     return RT_OK;
 }
 
@@ -178,13 +180,16 @@ int rt_init(int device, rt_ctx **out) {
         delete ctx;
         return RT_ERR_HIP;
     }
-    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&ctx->counter, sizeof(unsigned long long)) != hipSuccess ||
+    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&ctx->counter, 2 * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx;
         return RT_ERR_HIP;
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cus = prop.multiProcessorCount;
+    if (const char *e1 = std::getenv("RT_AMD_LDS_UNITS")) ctx->lds_limit_units = std::atoi(e1);
+    if (const char *e2 = std::getenv("RT_AMD_LEAF_T")) ctx->leaf_threshold = std::atoi(e2);
+    if (const char *e3 = std::getenv("RT_AMD_SHADE_T")) ctx->shade_threshold = std::atoi(e3);
     *out = ctx;
     return RT_OK;
 }
@@ -231,7 +236,7 @@ void rt_scene_free(rt_scene *scene) {
 
 int rt_scene_info(const rt_scene *scene, int32_t *out /* [4]: flat nodes, lights, f32 bytes, f64 bytes */) {
     if (!scene || !out) return RT_ERR_INVALID;
-    out[0] = scene->f32.sc.n_nodes;
+    out[0] = scene->f32.sc.n_units;
     out[1] = scene->f32.sc.n_lights;
     out[2] = (int32_t)scene->f32.bytes;
     out[3] = (int32_t)scene->f64.bytes;
@@ -254,8 +259,8 @@ int rt_trace_batch(rt_ctx *ctx, const rt_scene *scene, const rt_ray *rays, const
     if (e == hipSuccess) e = hipMemcpy(d_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice);
     if (e == hipSuccess && xi) e = hipMemcpy(d_xi, xi, n * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        if (precision == RT_PREC_F64) e = launch_trace<double>(scene->f64.sc, d_rays, d_xi, n, d_out, 0u, 0u, nullptr);
-        else e = launch_trace<float>(scene->f32.sc, d_rays, d_xi, n, d_out, 0u, 0u, nullptr);
+        if (precision == RT_PREC_F64) e = launch_trace<double>(scene->f64.sc, d_rays, d_xi, n, d_out, 0u, 0u, ctx->n_cus, nullptr);
+        else e = launch_trace<float>(scene->f32.sc, d_rays, d_xi, n, d_out, 0u, 0u, ctx->n_cus, nullptr);
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(out, d_out, n * sizeof(rt_hit), hipMemcpyDeviceToHost);
@@ -287,14 +292,15 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
         if (stats) *stats = rt_stats{0, 0, 0.0};
         return RT_OK;
     }
-    // Work decomposition: one wave per (8x8 pixel tile, sample chunk).  Enough chunks to give the 256 CUs several
-    // rounds of waves, but no chunk shorter than 16 samples (lanes regenerate paths inside a chunk).
+    // Work decomposition: a work item = (8x8 pixel tile, chunk of the sample range); waves pull items from a cursor.
+    // Enough chunks that every wave slot of the chip gets ~32 items (tail balance), but no chunk shorter than 24 samples
+    // (lanes regenerate paths inside a chunk; a short chunk wastes lanes while the last paths of an item finish).
     const int tiles = ((cam->image_width + 7) / 8) * ((cam->image_height + 7) / 8);
     int n_chunks = params->sample_chunks;
     if (n_chunks <= 0) {
-        const int want_waves = ctx->n_cus * 32 * 8;
-        n_chunks = (want_waves + tiles - 1) / tiles;
-        int max_chunks = n_samples / 16;
+        const int want_items = ctx->n_cus * 16 * 32;
+        n_chunks = (want_items + tiles - 1) / tiles;
+        int max_chunks = n_samples / 24;
         if (max_chunks < 1) max_chunks = 1;
         if (n_chunks > max_chunks) n_chunks = max_chunks;
     }
@@ -316,7 +322,10 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
     rl.s_end = s_end;
     rl.chunk_size = chunk_size;
     rl.n_chunks = n_chunks;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(unsigned long long), stream));
+    rl.n_cus = ctx->n_cus;
+    rl.leaf_threshold = ctx->leaf_threshold > 0 ? ctx->leaf_threshold : 16;
+    rl.shade_threshold = ctx->shade_threshold > 0 ? ctx->shade_threshold : 16;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counter, 0, 2 * sizeof(unsigned long long), stream));
     if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     if (params->precision == RT_PREC_F64)
         HIP_TRY(ctx, launch_render<double>(scene->f64.sc, convert_camera<double>(*cam), rl, target, ctx->counter, stream));

@@ -13,19 +13,16 @@
 namespace rtamd {
 
 template <class R> struct Flat {
-    std::vector<NodeT<R>> nodes;
-    std::vector<SphereT<R>> spheres;
-    std::vector<QuadT<R>> quads;
-    std::vector<TriT<R>> tris;
-    std::vector<MediumT<R>> media;
+    std::vector<UnitT<R>> stream; // threaded record stream (rt_scene.h)
+    std::vector<UnitT<R>> cold;   // parallel to `stream`: finalisation-only data
     std::vector<XformT<R>> xforms; // [0] = world (unused record)
     std::vector<MatT<R>> mats;
     std::vector<TexT<R>> texs;
     std::vector<ImageT> images;
     std::vector<PerlinT<R>> perlins;
     std::vector<LightT<R>> lights;
-    std::vector<int32_t> sphere_ids, quad_ids, tri_ids;
     int lights_is_list = 0;
+    int n_fused_boxes = 0;
 };
 
 // conversions double -> R; boxes are rounded outward so that an f32 box always contains the f64 one
@@ -49,7 +46,10 @@ template <class R> inline void cvt3(const double *s, R *d) {
 
 template <class R> class Flattener {
   public:
-    Flattener(const rt_scene_desc &d, Flat<R> &out, std::string &err) : d_(d), f_(out), err_(err) {}
+    // fuse_boxes: replace a hittable_list of six axis-aligned quads forming a closed box (quad.h:103 box()) by one
+    // AABOX record.  Used for the f32 stream only; the f64 parity stream keeps the reference's six quads.
+    Flattener(const rt_scene_desc &d, Flat<R> &out, std::string &err, bool fuse_boxes)
+        : d_(d), f_(out), err_(err), fuse_(fuse_boxes) {}
 
     int run() {
         int rc = validate();
@@ -65,7 +65,8 @@ template <class R> class Flattener {
     const rt_scene_desc &d_;
     Flat<R> &f_;
     std::string &err_;
-    static constexpr size_t kMaxNodes = size_t(1) << 26;
+    bool fuse_;
+    static constexpr size_t kMaxUnits = size_t(1) << 26;
 
     int fail(int code, const std::string &msg) {
         err_ = msg;
@@ -161,25 +162,6 @@ template <class R> class Flattener {
     }
 
     void convert_tables() {
-        f_.spheres.reserve(d_.n_spheres);
-        for (int i = 0; i < d_.n_spheres; i++) f_.spheres.push_back(cvt_sphere(d_.spheres[i]));
-        f_.quads.reserve(d_.n_quads);
-        for (int i = 0; i < d_.n_quads; i++) f_.quads.push_back(cvt_quad(d_.quads[i]));
-        f_.tris.reserve(d_.n_triangles);
-        for (int i = 0; i < d_.n_triangles; i++) {
-            const rt_triangle &t = d_.triangles[i];
-            TriT<R> o{};
-            cvt3(t.v0, o.v0);
-            cvt3(t.v1, o.v1);
-            cvt3(t.v2, o.v2);
-            cvt3(t.normal, o.n);
-            o.mat = t.mat;
-            o.cull = t.cull;
-            f_.tris.push_back(o);
-        }
-        f_.sphere_ids.assign(d_.n_spheres, -1);
-        f_.quad_ids.assign(d_.n_quads, -1);
-        f_.tri_ids.assign(d_.n_triangles, -1);
         for (int i = 0; i < d_.n_materials; i++) {
             const rt_material &m = d_.materials[i];
             MatT<R> o{};
@@ -215,43 +197,133 @@ template <class R> class Flattener {
         }
     }
 
-    int push(int kind, int index, const double *bbox) {
-        NodeT<R> n{};
-        if (bbox) {
+    static R I(int v) { return enc_int(v, R(0)); }
+    static R F(double x) {
+        R o;
+        cvt(x, o);
+        return o;
+    }
+
+    // append a record of `n` units; returns its unit offset
+    int push_units(int n, int node_id) {
+        int off = (int)f_.stream.size();
+        UnitT<R> z{};
+        f_.stream.insert(f_.stream.end(), n, z);
+        f_.cold.insert(f_.cold.end(), n, z);
+        f_.cold[off].w[3] = I(node_id);
+        return off;
+    }
+
+    // Is description node `id` a hittable_list of six axis-aligned quads that form a closed box with one material?
+    // On success fills lo/hi, the material, face_id[2*axis+side] (description node of that face) and the bit mask of
+    // faces whose stored normal points out of the box.
+    bool match_box(int id, double lo[3], double hi[3], int &mat, int face_id[6], int &outward_mask) const {
+        const rt_node &n = d_.nodes[id];
+        if (n.kind != RT_NODE_LIST || n.b != 6) return false;
+        for (int a = 0; a < 3; a++) {
+            lo[a] = INFINITY;
+            hi[a] = -INFINITY;
+        }
+        mat = -2;
+        int axis_of[6];
+        for (int k = 0; k < 6; k++) {
+            const rt_node &c = d_.nodes[d_.child_index[n.a + k]];
+            if (c.kind != RT_NODE_QUAD) return false;
+            const rt_quad &q = d_.quads[c.a];
+            if (q.mat < 0 || (mat != -2 && q.mat != mat)) return false;
+            mat = q.mat;
+            int au = -1, av = -1;
             for (int a = 0; a < 3; a++) {
-                cvt_lo(bbox[2 * a], n.bmin[a]);
-                cvt_hi(bbox[2 * a + 1], n.bmax[a]);
+                if (q.u[a] != 0.0) {
+                    if (au >= 0) return false;
+                    au = a;
+                }
+                if (q.v[a] != 0.0) {
+                    if (av >= 0) return false;
+                    av = a;
+                }
+            }
+            if (au < 0 || av < 0 || au == av) return false;
+            axis_of[k] = 3 - au - av;
+            for (int a = 0; a < 3; a++) {
+                const double c0 = q.Q[a], c1 = q.Q[a] + q.u[a], c2 = q.Q[a] + q.v[a], c3 = q.Q[a] + q.u[a] + q.v[a];
+                lo[a] = std::fmin(lo[a], std::fmin(std::fmin(c0, c1), std::fmin(c2, c3)));
+                hi[a] = std::fmax(hi[a], std::fmax(std::fmax(c0, c1), std::fmax(c2, c3)));
             }
         }
-        n.meta = make_meta(kind, index);
-        n.skip = (int)f_.nodes.size() + 1;
-        f_.nodes.push_back(n);
-        return (int)f_.nodes.size() - 1;
+        if (tex_needs_uv(d_.materials[mat].tex)) return false; // rec.u, rec.v of the faces would be needed
+        double ext = 0;
+        for (int a = 0; a < 3; a++) {
+            if (!(hi[a] > lo[a])) return false;
+            ext = std::fmax(ext, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
+        }
+        const double tol = 1e-9 * ext;
+        for (int f = 0; f < 6; f++) face_id[f] = -1;
+        outward_mask = 0;
+        for (int k = 0; k < 6; k++) {
+            const int cid = d_.child_index[n.a + k];
+            const rt_quad &q = d_.quads[d_.nodes[cid].a];
+            const int c = axis_of[k];
+            int side;
+            if (std::fabs(q.Q[c] - lo[c]) <= tol) side = 0;
+            else if (std::fabs(q.Q[c] - hi[c]) <= tol) side = 1;
+            else return false;
+            for (int a = 0; a < 3; a++) { // the face must span the whole box in its two in-plane axes
+                if (a == c) continue;
+                const double e0 = std::fmin(q.Q[a], q.Q[a] + q.u[a] + q.v[a]), e1 = std::fmax(q.Q[a], q.Q[a] + q.u[a] + q.v[a]);
+                if (std::fabs(e0 - lo[a]) > tol || std::fabs(e1 - hi[a]) > tol) return false;
+            }
+            const int f = 2 * c + side;
+            if (face_id[f] >= 0) return false;
+            face_id[f] = cid;
+            const bool outward = side ? q.normal[c] > 0 : q.normal[c] < 0;
+            if (outward) outward_mask |= 1 << f;
+        }
+        return true;
     }
 
     // Emit the subtree of description node `id` in the reference's visiting order.
     int emit(int id, int ctx, int rdepth) {
         if (rdepth > 256) return fail(RT_ERR_INVALID, "scene graph too deep (cycle?)");
-        if (f_.nodes.size() > kMaxNodes) return fail(RT_ERR_NOMEM, "flattened scene too large");
+        if (f_.stream.size() > kMaxUnits) return fail(RT_ERR_NOMEM, "flattened scene too large");
         const rt_node &n = d_.nodes[id];
         switch (n.kind) {
         case RT_NODE_BVH: { // bvh.h:43-51: own box, then left, then right
-            int self = push(K_BOX, 0, n.bbox);
+            const int self = push_units(2, id);
+            R lo[3], hi[3];
+            for (int a = 0; a < 3; a++) {
+                cvt_lo(n.bbox[2 * a], lo[a]);
+                cvt_hi(n.bbox[2 * a + 1], hi[a]);
+            }
+            f_.stream[self] = UnitT<R>{{lo[0], lo[1], lo[2], hi[0]}};
+            f_.stream[self + 1] = UnitT<R>{{hi[1], hi[2], I(0), I(make_hdr(K_BOX, 0))}};
             int rc = emit(n.a, ctx, rdepth + 1);
             if (rc) return rc;
             if (n.b != n.a) { // span-1 nodes have left == right (bvh.h:30): the second visit cannot change the result
                 rc = emit(n.b, ctx, rdepth + 1);
                 if (rc) return rc;
             }
-            f_.nodes[self].skip = (int)f_.nodes.size();
+            f_.stream[self + 1].w[2] = I((int)f_.stream.size());
             return RT_OK;
         }
-        case RT_NODE_LIST: // hittable_list.h:29: children in insertion order, each against the closest hit so far
+        case RT_NODE_LIST: { // hittable_list.h:29: children in insertion order, each against the closest hit so far
+            double lo[3], hi[3];
+            int mat, face_id[6], outward;
+            if (fuse_ && match_box(id, lo, hi, mat, face_id, outward)) {
+                const int off = push_units(2, id);
+                f_.stream[off] = UnitT<R>{{F(lo[0]), F(lo[1]), F(lo[2]), F(hi[0])}};
+                f_.stream[off + 1] = UnitT<R>{{F(hi[1]), F(hi[2]), I(mat), I(make_hdr(K_AABOX, outward))}};
+                f_.cold[off] = UnitT<R>{{I(face_id[0]), I(face_id[1]), I(face_id[2]), I(face_id[3])}};
+                f_.cold[off + 1] = UnitT<R>{{I(face_id[4]), I(face_id[5]), I(0), I(0)}};
+                f_.n_fused_boxes++;
+                return RT_OK;
+            }
             for (int k = 0; k < n.b; k++) {
                 int rc = emit(d_.child_index[n.a + k], ctx, rdepth + 1);
                 if (rc) return rc;
             }
             return RT_OK;
+        }
         case RT_NODE_TRANSLATE:
         case RT_NODE_ROTATE_Y: {
             const XformT<R> parent = f_.xforms[ctx];
@@ -272,40 +344,61 @@ template <class R> class Flattener {
                 cvt(n.p[1], x.p[1]);
             }
             f_.xforms.push_back(x);
-            push(K_XF_ENTER, c, nullptr);
+            const int en = push_units(2, id);
+            f_.stream[en] = UnitT<R>{{x.p[0], x.p[1], x.p[2], R(0)}};
+            f_.stream[en + 1] = UnitT<R>{{I(x.kind), I(c), I(0), I(make_hdr(K_XF_ENTER, 0))}};
             int rc = emit(n.a, c, rdepth + 1);
             if (rc) return rc;
-            push(K_XF_EXIT, c, nullptr);
+            const int ex = push_units(2, id);
+            f_.stream[ex + 1] = UnitT<R>{{I(0), I(ctx), I(0), I(make_hdr(K_XF_EXIT, 0))}};
             return RT_OK;
         }
         case RT_NODE_MEDIUM: {
             const rt_node &b = d_.nodes[n.a];
             if (b.kind != RT_NODE_SPHERE)
                 return fail(RT_ERR_UNSUPPORTED, "constant_medium boundary must be a sphere on the device path");
-            MediumT<R> m{};
-            cvt(n.p[0], m.neg_inv_density);
-            m.sphere = b.a;
-            m.mat = n.b;
-            m.node_id = id;
-            f_.media.push_back(m);
-            push(K_MEDIUM, (int)f_.media.size() - 1, nullptr);
+            const rt_sphere &s = d_.spheres[b.a];
+            if (s.dcenter[0] != 0 || s.dcenter[1] != 0 || s.dcenter[2] != 0)
+                return fail(RT_ERR_UNSUPPORTED, "constant_medium boundary must be a static sphere on the device path");
+            const int off = push_units(2, id);
+            f_.stream[off] = UnitT<R>{{F(s.center[0]), F(s.center[1]), F(s.center[2]), F(s.radius)}};
+            f_.stream[off + 1] = UnitT<R>{{F(n.p[0]), I(n.b), I(id), I(make_hdr(K_MEDIUM, 0))}};
             return RT_OK;
         }
-        case RT_NODE_SPHERE:
-            f_.sphere_ids[n.a] = id;
-            if (d_.spheres[n.a].mat < 0) return fail(RT_ERR_INVALID, "world sphere without material");
-            push(K_SPHERE, n.a, nullptr);
+        case RT_NODE_SPHERE: {
+            const rt_sphere &s = d_.spheres[n.a];
+            if (s.mat < 0) return fail(RT_ERR_INVALID, "world sphere without material");
+            const bool moving = s.dcenter[0] != 0 || s.dcenter[1] != 0 || s.dcenter[2] != 0;
+            const int off = push_units(moving ? 3 : 2, id);
+            f_.stream[off] = UnitT<R>{{F(s.center[0]), F(s.center[1]), F(s.center[2]), F(s.radius)}};
+            f_.stream[off + 1] = UnitT<R>{{I(s.mat), I(0), I(0), I(make_hdr(K_SPHERE, moving ? 1 : 0))}};
+            if (moving) f_.stream[off + 2] = UnitT<R>{{F(s.dcenter[0]), F(s.dcenter[1]), F(s.dcenter[2]), R(0)}};
             return RT_OK;
-        case RT_NODE_QUAD:
-            f_.quad_ids[n.a] = id;
-            if (d_.quads[n.a].mat < 0) return fail(RT_ERR_INVALID, "world quad without material");
-            push(K_QUAD, n.a, nullptr);
+        }
+        case RT_NODE_QUAD: {
+            const rt_quad &q = d_.quads[n.a];
+            if (q.mat < 0) return fail(RT_ERR_INVALID, "world quad without material");
+            const int off = push_units(5, id);
+            f_.stream[off] = UnitT<R>{{F(q.normal[0]), F(q.normal[1]), F(q.normal[2]), F(q.D)}};
+            f_.stream[off + 1] = UnitT<R>{{F(q.Q[0]), F(q.Q[1]), F(q.Q[2]), I(make_hdr(K_QUAD, 0))}};
+            f_.stream[off + 2] = UnitT<R>{{F(q.u[0]), F(q.u[1]), F(q.u[2]), I(q.mat)}};
+            f_.stream[off + 3] = UnitT<R>{{F(q.v[0]), F(q.v[1]), F(q.v[2]), F(q.area)}};
+            f_.stream[off + 4] = UnitT<R>{{F(q.w[0]), F(q.w[1]), F(q.w[2]), R(0)}};
             return RT_OK;
-        case RT_NODE_TRIANGLE:
-            f_.tri_ids[n.a] = id;
-            if (d_.triangles[n.a].mat < 0) return fail(RT_ERR_INVALID, "world triangle without material");
-            push(K_TRI, n.a, nullptr);
+        }
+        case RT_NODE_TRIANGLE: {
+            const rt_triangle &t = d_.triangles[n.a];
+            if (t.mat < 0) return fail(RT_ERR_INVALID, "world triangle without material");
+            // triangle.h:24-25 computes the edges from the double vertices at every hit(); the same subtraction here
+            const double e1[3] = {t.v1[0] - t.v0[0], t.v1[1] - t.v0[1], t.v1[2] - t.v0[2]};
+            const double e2[3] = {t.v2[0] - t.v0[0], t.v2[1] - t.v0[1], t.v2[2] - t.v0[2]};
+            const int off = push_units(3, id);
+            f_.stream[off] = UnitT<R>{{F(t.v0[0]), F(t.v0[1]), F(t.v0[2]), F(e1[0])}};
+            f_.stream[off + 1] = UnitT<R>{{F(e1[1]), F(e1[2]), F(e2[0]), I(make_hdr(K_TRI, 0))}};
+            f_.stream[off + 2] = UnitT<R>{{F(e2[1]), F(e2[2]), I(t.mat), I(t.cull)}};
+            f_.cold[off] = UnitT<R>{{F(t.normal[0]), F(t.normal[1]), F(t.normal[2]), I(id)}};
             return RT_OK;
+        }
         }
         return fail(RT_ERR_INVALID, "bad node kind");
     }

@@ -135,42 +135,115 @@ template <class R> struct Rng {
     }
 };
 
+// ------------------------------------------------------------------------------------------------ scene memory
+// The leading sc.lds_units units of the record stream live in LDS (staged by stage_stream()), the rest in global
+// memory.  ALL_LDS = the whole stream fits: no per-load address-space branch.
+extern __shared__ __attribute__((aligned(16))) unsigned char rt_smem[];
+
+template <class R> RT_DEV int ldi(R x) { return dec_int(x); }
+
+// A unit always moves as whole 16-byte vectors (ds_read_b128 / global_load_dwordx4), never as scalar pieces.
+typedef float rt_f4 __attribute__((ext_vector_type(4)));
+typedef double rt_d2 __attribute__((ext_vector_type(2)));
+RT_DEV UnitT<float> ld_unit(const UnitT<float> *p) {
+    const rt_f4 v = *reinterpret_cast<const rt_f4 *>(p);
+    return UnitT<float>{{v.x, v.y, v.z, v.w}};
+}
+RT_DEV UnitT<double> ld_unit(const UnitT<double> *p) {
+    const rt_d2 a = reinterpret_cast<const rt_d2 *>(p)[0], b = reinterpret_cast<const rt_d2 *>(p)[1];
+    return UnitT<double>{{a.x, a.y, b.x, b.y}};
+}
+
+template <class R, bool ALL_LDS> struct Mem {
+    const UnitT<R> *glob;
+    int lds_units;
+    RT_DEV UnitT<R> ld(int off) const {
+        const UnitT<R> *l = reinterpret_cast<const UnitT<R> *>(rt_smem);
+        if constexpr (ALL_LDS) {
+            return ld_unit(l + off);
+        } else {
+            UnitT<R> u;
+            if (off < lds_units) {
+                u = ld_unit(l + off);
+            } else {
+                asm volatile("" : "+v"(off)); // keep the two address spaces in separate blocks (no pointer select -> flat load)
+                u = ld_unit(glob + off);
+            }
+            return u;
+        }
+    }
+};
+
+template <class R> RT_DEV void stage_stream(const SceneT<R> &sc) {
+    UnitT<R> *l = reinterpret_cast<UnitT<R> *>(rt_smem);
+    for (int k = threadIdx.x; k < sc.lds_units; k += blockDim.x) l[k] = sc.stream[k];
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------ intersection
-template <class R> RT_DEV bool box_hit(const NodeT<R> &nd, const RayT<R> &r, V3<R> inv, R tmin, R tmax) { // aabb.h:36
-    {
-        R t0 = (nd.bmin[0] - r.o.x) * inv.x, t1 = (nd.bmax[0] - r.o.x) * inv.x;
-        if (t0 < t1) { if (t0 > tmin) tmin = t0; if (t1 < tmax) tmax = t1; }
-        else { if (t1 > tmin) tmin = t1; if (t0 < tmax) tmax = t0; }
-        if (tmax <= tmin) return false;
+// aabb::hit (aabb.h:36) over the interval (tmin, tmax).  The double path keeps the reference's statement order; the
+// float path computes the same slab distances and folds them with min/max.
+template <class R>
+RT_DEV bool box_hit(const UnitT<R> &u0, const UnitT<R> &u1, V3<R> o, V3<R> inv, R tmin, R tmax) {
+    const R bx0 = u0.w[0], by0 = u0.w[1], bz0 = u0.w[2], bx1 = u0.w[3], by1 = u1.w[0], bz1 = u1.w[1];
+    if constexpr (sizeof(R) == 4) {
+        R tx0 = (bx0 - o.x) * inv.x, tx1 = (bx1 - o.x) * inv.x;
+        R ty0 = (by0 - o.y) * inv.y, ty1 = (by1 - o.y) * inv.y;
+        R tz0 = (bz0 - o.z) * inv.z, tz1 = (bz1 - o.z) * inv.z;
+        R tn = m_max(m_max(m_min(tx0, tx1), m_min(ty0, ty1)), m_max(m_min(tz0, tz1), tmin));
+        R tf = m_min(m_min(m_max(tx0, tx1), m_max(ty0, ty1)), m_min(m_max(tz0, tz1), tmax));
+        return tf > tn;
+    } else {
+        {
+            R t0 = (bx0 - o.x) * inv.x, t1 = (bx1 - o.x) * inv.x;
+            if (t0 < t1) { if (t0 > tmin) tmin = t0; if (t1 < tmax) tmax = t1; }
+            else { if (t1 > tmin) tmin = t1; if (t0 < tmax) tmax = t0; }
+            if (tmax <= tmin) return false;
+        }
+        {
+            R t0 = (by0 - o.y) * inv.y, t1 = (by1 - o.y) * inv.y;
+            if (t0 < t1) { if (t0 > tmin) tmin = t0; if (t1 < tmax) tmax = t1; }
+            else { if (t1 > tmin) tmin = t1; if (t0 < tmax) tmax = t0; }
+            if (tmax <= tmin) return false;
+        }
+        {
+            R t0 = (bz0 - o.z) * inv.z, t1 = (bz1 - o.z) * inv.z;
+            if (t0 < t1) { if (t0 > tmin) tmin = t0; if (t1 < tmax) tmax = t1; }
+            else { if (t1 > tmin) tmin = t1; if (t0 < tmax) tmax = t0; }
+            if (tmax <= tmin) return false;
+        }
+        return true;
     }
-    {
-        R t0 = (nd.bmin[1] - r.o.y) * inv.y, t1 = (nd.bmax[1] - r.o.y) * inv.y;
-        if (t0 < t1) { if (t0 > tmin) tmin = t0; if (t1 < tmax) tmax = t1; }
-        else { if (t1 > tmin) tmin = t1; if (t0 < tmax) tmax = t0; }
-        if (tmax <= tmin) return false;
-    }
-    {
-        R t0 = (nd.bmin[2] - r.o.z) * inv.z, t1 = (nd.bmax[2] - r.o.z) * inv.z;
-        if (t0 < t1) { if (t0 > tmin) tmin = t0; if (t1 < tmax) tmax = t1; }
-        else { if (t1 > tmin) tmin = t1; if (t0 < tmax) tmax = t0; }
-        if (tmax <= tmin) return false;
-    }
+}
+
+// Fused box() primitive (f32 stream only): the six quads of quad.h:103 as one slab test.  The ray meets the box
+// surface at the slab entry and exit distances; quad::hit accepts tmin <= t <= tmax (interval::contains, quad.h:41).
+template <class R>
+RT_DEV bool aabox_t(const UnitT<R> &u0, const UnitT<R> &u1, V3<R> o, V3<R> inv, R tmin, R tmax, R &t_out) {
+    R tx0 = (u0.w[0] - o.x) * inv.x, tx1 = (u0.w[3] - o.x) * inv.x;
+    R ty0 = (u0.w[1] - o.y) * inv.y, ty1 = (u1.w[0] - o.y) * inv.y;
+    R tz0 = (u0.w[2] - o.z) * inv.z, tz1 = (u1.w[1] - o.z) * inv.z;
+    R tn = m_max(m_max(m_min(tx0, tx1), m_min(ty0, ty1)), m_min(tz0, tz1));
+    R tf = m_min(m_min(m_max(tx0, tx1), m_max(ty0, ty1)), m_max(tz0, tz1));
+    if (!(tf >= tn)) return false;
+    R t = tn >= tmin ? tn : tf;
+    if (!(tmin <= t && t <= tmax)) return false;
+    t_out = t;
     return true;
 }
 
-template <class R> RT_DEV bool sphere_t(const SphereT<R> &s, const RayT<R> &r, R tmin, R tmax, R &t_out) { // sphere.h:29
-    V3<R> cc = ld3(s.c) + scale<R>(r.tm, ld3(s.d));
-    V3<R> oc = cc - r.o;
-    R a = len2(r.d);
-    R h = dot(r.d, oc);
-    R c = len2(oc) - s.radius * s.radius;
+template <class R> RT_DEV bool sphere_t(V3<R> cc, R radius, V3<R> ro, V3<R> rd, R tmin, R tmax, R &t_out) { // sphere.h:29
+    V3<R> oc = cc - ro;
+    R a = len2(rd);
+    R h = dot(rd, oc);
+    R c = len2(oc) - radius * radius;
     if constexpr (sizeof(R) == 4) {
         // Same quadratic, conditioned for float: h*h - a*c cancels catastrophically when |oc| >> radius (first_scene's
         // r=1 light 1000 units away, the r=1000 ground, final_scene's r=5000 fog).  disc = a*(r^2 - |oc - (h/a)d|^2) and
         // the roots c/q, q/a with q = h + sign(h)*sqrt(disc) are algebraically identical and lose no digits.
         R inva = R(1) / a;
-        V3<R> perp = oc - scale<R>(h * inva, r.d);
-        R disc = a * (s.radius * s.radius - len2(perp));
+        V3<R> perp = oc - scale<R>(h * inva, rd);
+        R disc = a * (radius * radius - len2(perp));
         if (disc < R(0)) return false;
         R sq = m_sqrt(disc);
         R q = h + (h < R(0) ? -sq : sq);
@@ -197,39 +270,43 @@ template <class R> RT_DEV bool sphere_t(const SphereT<R> &s, const RayT<R> &r, R
         return true;
     }
 }
+template <class R> RT_DEV bool sphere_t(const SphereT<R> &s, const RayT<R> &r, R tmin, R tmax, R &t_out) {
+    return sphere_t(ld3(s.c) + scale<R>(r.tm, ld3(s.d)), s.radius, r.o, r.d, tmin, tmax, t_out);
+}
 
 template <class R>
-RT_DEV bool quad_t(const QuadT<R> &q, const RayT<R> &r, R tmin, R tmax, R &t_out, R &alpha, R &beta) { // quad.h:32
-    V3<R> n = ld3(q.n);
-    R denom = dot(n, r.d);
+RT_DEV bool quad_t(V3<R> n, R D, V3<R> Q, V3<R> qu, V3<R> qv, V3<R> w, V3<R> ro, V3<R> rd, R tmin, R tmax, R &t_out, R &alpha,
+                   R &beta) { // quad.h:32
+    R denom = dot(n, rd);
     if (m_abs(denom) < R(1e-8)) return false;
-    R t = (q.D - dot(n, r.o)) / denom;
+    R t = (D - dot(n, ro)) / denom;
     if (!(tmin <= t && t <= tmax)) return false; // interval::contains
-    V3<R> ph = ray_at(r, t) - ld3(q.Q);
-    V3<R> w = ld3(q.w);
-    alpha = dot(w, cross(ph, ld3(q.v)));
-    beta = dot(w, cross(ld3(q.u), ph));
+    V3<R> ph = (ro + scale<R>(t, rd)) - Q;
+    alpha = dot(w, cross(ph, qv));
+    beta = dot(w, cross(qu, ph));
     if (!(R(0) <= alpha && alpha <= R(1)) || !(R(0) <= beta && beta <= R(1))) return false; // quad.h:62
     t_out = t;
     return true;
 }
+template <class R>
+RT_DEV bool quad_t(const QuadT<R> &q, const RayT<R> &r, R tmin, R tmax, R &t_out, R &alpha, R &beta) {
+    return quad_t(ld3(q.n), q.D, ld3(q.Q), ld3(q.u), ld3(q.v), ld3(q.w), r.o, r.d, tmin, tmax, t_out, alpha, beta);
+}
 
 template <class R>
-RT_DEV bool tri_t(const TriT<R> &tr, const RayT<R> &r, R tmin, R tmax, R &t_out, float &u_out, float &v_out) { // triangle.h:23
+RT_DEV bool tri_t(V3<R> v0, V3<R> edge1, V3<R> edge2, int cull, V3<R> ro, V3<R> rd, R tmin, R tmax, R &t_out, float &u_out,
+                  float &v_out) { // triangle.h:23
     const float EPSILON = 0.000001; // triangle.h:16 (const float): a, f, u, v, t are float in the reference
-    V3<R> v0 = ld3(tr.v0);
-    V3<R> edge1 = ld3(tr.v1) - v0;
-    V3<R> edge2 = ld3(tr.v2) - v0;
-    V3<R> h = cross(r.d, edge2);
+    V3<R> h = cross(rd, edge2);
     float a = (float)dot(edge1, h);
-    if (tr.cull && a < EPSILON) return false;
+    if (cull && a < EPSILON) return false;
     if (fabsf(a) < EPSILON) return false;
     float f = (float)(R(1.0) / R(a));
-    V3<R> s = r.o - v0;
+    V3<R> s = ro - v0;
     float u = (float)(R(f) * dot(s, h));
     if (u < 0.0f || u > 1.0f) return false;
     V3<R> q = cross(s, edge1);
-    float v = (float)(R(f) * dot(r.d, q));
+    float v = (float)(R(f) * dot(rd, q));
     if (v < 0.0f || u + v > 1.0f) return false;
     float t = (float)(R(f) * dot(edge2, q));
     if (!(tmin <= R(t) && R(t) <= tmax)) return false;
@@ -239,108 +316,156 @@ RT_DEV bool tri_t(const TriT<R> &tr, const RayT<R> &r, R tmin, R tmax, R &t_out,
     return true;
 }
 
+// constant_medium.h:21 (boundary is a static sphere); the uniform is drawn only where the reference draws it (line 41)
 template <class R, class XiFn>
-RT_DEV bool medium_t(const SceneT<R> &sc, const MediumT<R> &m, const RayT<R> &r, R tmin, R tmax, XiFn xi_fn, R &t_out) {
-    // constant_medium.h:21 (boundary is a sphere); the uniform is drawn only where the reference draws it (line 41)
-    const SphereT<R> s = sc.spheres[m.sphere];
+RT_DEV bool medium_t(V3<R> cc, R radius, R neg_inv_density, int node_id, V3<R> ro, V3<R> rd, R tmin, R tmax, XiFn xi_fn,
+                     R &t_out) {
     R t1, t2;
-    if (!sphere_t(s, r, -Const<R>::inf, Const<R>::inf, t1)) return false;
-    if (!sphere_t(s, r, t1 + R(0.0001), Const<R>::inf, t2)) return false;
+    if (!sphere_t(cc, radius, ro, rd, -Const<R>::inf, Const<R>::inf, t1)) return false;
+    if (!sphere_t(cc, radius, ro, rd, t1 + R(0.0001), Const<R>::inf, t2)) return false;
     if (t1 < tmin) t1 = tmin;
     if (t2 > tmax) t2 = tmax;
     if (t1 >= t2) return false;
     if (t1 < R(0)) t1 = R(0);
-    R ray_length = len(r.d);
+    R ray_length = len(rd);
     R distance_inside_boundary = (t2 - t1) * ray_length;
-    R hit_distance = m.neg_inv_density * m_log(xi_fn(m.node_id));
+    R hit_distance = neg_inv_density * m_log(xi_fn(node_id));
     if (hit_distance > distance_inside_boundary) return false;
     t_out = t1 + hit_distance / ray_length;
     return true;
 }
 
-template <class R> RT_DEV RayT<R> xf_apply(const XformT<R> &x, const RayT<R> &r) {
-    RayT<R> o;
-    o.tm = r.tm;
-    if (x.kind == XF_TRANSLATE) { // hittable.h:55
-        o.o = r.o - mk<R>(x.p[0], x.p[1], x.p[2]);
-        o.d = r.d;
+template <class R> RT_DEV void xf_apply(int kind, R p0, R p1, R p2, V3<R> &o, V3<R> &d) {
+    if (kind == XF_TRANSLATE) { // hittable.h:55
+        o = o - mk<R>(p0, p1, p2);
     } else { // hittable.h:114-124
-        R s = x.p[0], c = x.p[1];
-        o.o = mk<R>((c * r.o.x) - (s * r.o.z), r.o.y, (s * r.o.x) + (c * r.o.z));
-        o.d = mk<R>((c * r.d.x) - (s * r.d.z), r.d.y, (s * r.d.x) + (c * r.d.z));
+        R s = p0, c = p1;
+        o = mk<R>((c * o.x) - (s * o.z), o.y, (s * o.x) + (c * o.z));
+        d = mk<R>((c * d.x) - (s * d.z), d.y, (s * d.x) + (c * d.z));
     }
-    return o;
 }
 
 template <class R> RT_DEV RayT<R> ray_in_ctx(const SceneT<R> &sc, const RayT<R> &world, int ctx) {
     RayT<R> r = world;
     if (ctx != 0) {
         const int depth = sc.xforms[ctx].depth;
-        for (int k = 0; k < depth; k++) r = xf_apply(sc.xforms[sc.xforms[ctx].chain[k]], r);
+        for (int k = 0; k < depth; k++) {
+            const XformT<R> x = sc.xforms[sc.xforms[ctx].chain[k]];
+            xf_apply(x.kind, x.p[0], x.p[1], x.p[2], r.o, r.d);
+        }
     }
     return r;
 }
 
 template <class R> RT_DEV V3<R> inv_dir(V3<R> d) { return mk<R>(R(1.0) / d.x, R(1.0) / d.y, R(1.0) / d.z); } // aabb.h:42
 
-template <class R> struct Best {
-    R t;
-    int meta; // -1 = miss
+// Per-ray traversal state of world.hit(r, interval(tmin, inf), rec): a cursor into the threaded stream (pre-order ==
+// the reference's recursion order), the ray in the current transform context and the closest hit so far.
+template <class R> struct Trav {
+    V3<R> o, d, inv; // ray in the space of context `ctx`
+    R best_t;
+    int best_off; // stream offset of the winning record, -1 = miss
+    int best_ctx;
     int ctx;
+    int i; // cursor (unit offset); >= n_units: traversal finished
+    // the record at the cursor
+    UnitT<R> u0, u1;
+    int hdr;
 };
 
-// world.hit(r, interval(tmin, tmax), rec): threaded pre-order walk == the reference's recursion order.
-template <class R, class MediumXi>
-RT_DEV Best<R> traverse(const SceneT<R> &sc, const RayT<R> &world, R tmin, R tmax, MediumXi medium_xi) {
-    Best<R> best;
-    best.t = tmax;
-    best.meta = -1;
-    best.ctx = 0;
-    RayT<R> ray = world;
-    V3<R> inv = inv_dir(ray.d);
-    int ctx = 0;
-    int i = 0;
-    const int n = sc.n_nodes;
-    while (i < n) {
-        const NodeT<R> nd = sc.nodes[i];
-        const int kind = nd.meta & 15, idx = nd.meta >> 4;
-        if (kind == K_BOX) {
-            i = box_hit(nd, ray, inv, tmin, best.t) ? i + 1 : nd.skip;
-            continue;
-        }
-        i++;
-        if (kind == K_SPHERE) {
-            R t;
-            if (sphere_t(sc.spheres[idx], ray, tmin, best.t, t)) { best.t = t; best.meta = nd.meta; best.ctx = ctx; }
-        } else if (kind == K_QUAD) {
-            R t, al, be;
-            if (quad_t(sc.quads[idx], ray, tmin, best.t, t, al, be)) { best.t = t; best.meta = nd.meta; best.ctx = ctx; }
-        } else if (kind == K_TRI) {
-            R t;
-            float u, v;
-            if (tri_t(sc.tris[idx], ray, tmin, best.t, t, u, v)) { best.t = t; best.meta = nd.meta; best.ctx = ctx; }
-        } else if (kind == K_MEDIUM) {
-            const MediumT<R> m = sc.media[idx];
-            R t;
-            if (medium_t(sc, m, ray, tmin, best.t, medium_xi, t)) { best.t = t; best.meta = nd.meta; best.ctx = ctx; }
-        } else if (kind == K_XF_ENTER) {
-            ray = xf_apply(sc.xforms[idx], ray);
-            inv = inv_dir(ray.d);
-            ctx = idx;
-        } else { // K_XF_EXIT
-            ctx = sc.xforms[idx].parent;
-            ray = ray_in_ctx(sc, world, ctx);
-            inv = inv_dir(ray.d);
-        }
+template <class R, bool ALL_LDS> RT_DEV void trav_goto(const Mem<R, ALL_LDS> &mem, int n_units, Trav<R> &tv, int i) {
+    tv.i = i;
+    if (i < n_units) {
+        tv.u0 = mem.ld(i);
+        tv.u1 = mem.ld(i + 1);
+        tv.hdr = ldi(tv.u1.w[3]);
     }
-    return best;
+}
+
+template <class R, bool ALL_LDS>
+RT_DEV void trav_begin(const Mem<R, ALL_LDS> &mem, int n_units, Trav<R> &tv, const RayT<R> &world) {
+    tv.o = world.o;
+    tv.d = world.d;
+    tv.inv = inv_dir(world.d);
+    tv.best_t = Const<R>::inf;
+    tv.best_off = -1;
+    tv.best_ctx = 0;
+    tv.ctx = 0;
+    trav_goto(mem, n_units, tv, 0);
+}
+
+// One BOX record: descend (next record) or take the skip link.
+template <class R, bool ALL_LDS>
+RT_DEV void trav_box_step(const Mem<R, ALL_LDS> &mem, int n_units, Trav<R> &tv, R tmin) {
+    const bool hit = box_hit(tv.u0, tv.u1, tv.o, tv.inv, tmin, tv.best_t);
+    trav_goto(mem, n_units, tv, hit ? tv.i + 2 : ldi(tv.u1.w[2]));
+}
+
+// One non-BOX record.
+template <class R, bool ALL_LDS, class MediumXi>
+RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, Trav<R> &tv, const RayT<R> &world, R tmin,
+                           MediumXi medium_xi) {
+    const int kind = tv.hdr & 15;
+    const int i = tv.i;
+    int next = i + 2;
+    if (kind == K_SPHERE) {
+        V3<R> cc = mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]);
+        if (tv.hdr >> 4) { // moving sphere: centre = c + time*d (sphere.h:30)
+            const UnitT<R> u2 = mem.ld(i + 2);
+            cc = cc + scale<R>(world.tm, mk<R>(u2.w[0], u2.w[1], u2.w[2]));
+            next = i + 3;
+        } else if constexpr (sizeof(R) == 8) {
+            cc = cc + scale<R>(world.tm, mk<R>(R(0), R(0), R(0))); // the reference always evaluates center.at(time)
+        }
+        R t;
+        if (sphere_t(cc, tv.u0.w[3], tv.o, tv.d, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = i; tv.best_ctx = tv.ctx; }
+    } else if (kind == K_AABOX) {
+        R t;
+        if (aabox_t(tv.u0, tv.u1, tv.o, tv.inv, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = i; tv.best_ctx = tv.ctx; }
+    } else if (kind == K_QUAD) {
+        const UnitT<R> u2 = mem.ld(i + 2), u3 = mem.ld(i + 3), u4 = mem.ld(i + 4);
+        R t, al, be;
+        if (quad_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], mk<R>(tv.u1.w[0], tv.u1.w[1], tv.u1.w[2]),
+                   mk<R>(u2.w[0], u2.w[1], u2.w[2]), mk<R>(u3.w[0], u3.w[1], u3.w[2]), mk<R>(u4.w[0], u4.w[1], u4.w[2]), tv.o, tv.d,
+                   tmin, tv.best_t, t, al, be)) {
+            tv.best_t = t; tv.best_off = i; tv.best_ctx = tv.ctx;
+        }
+        next = i + 5;
+    } else if (kind == K_TRI) {
+        const UnitT<R> u2 = mem.ld(i + 2);
+        R t;
+        float u, v;
+        if (tri_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), mk<R>(tv.u0.w[3], tv.u1.w[0], tv.u1.w[1]),
+                  mk<R>(tv.u1.w[2], u2.w[0], u2.w[1]), ldi(u2.w[3]), tv.o, tv.d, tmin, tv.best_t, t, u, v)) {
+            tv.best_t = t; tv.best_off = i; tv.best_ctx = tv.ctx;
+        }
+        next = i + 3;
+    } else if (kind == K_MEDIUM) {
+        R t;
+        if (medium_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], tv.u1.w[0], ldi(tv.u1.w[2]), tv.o, tv.d, tmin,
+                     tv.best_t, medium_xi, t)) {
+            tv.best_t = t; tv.best_off = i; tv.best_ctx = tv.ctx;
+        }
+    } else if (kind == K_XF_ENTER) {
+        xf_apply(ldi(tv.u1.w[0]), tv.u0.w[0], tv.u0.w[1], tv.u0.w[2], tv.o, tv.d);
+        tv.inv = inv_dir(tv.d);
+        tv.ctx = ldi(tv.u1.w[1]);
+    } else if (kind == K_XF_EXIT) {
+        tv.ctx = ldi(tv.u1.w[1]);
+        const RayT<R> r = ray_in_ctx(sc, world, tv.ctx);
+        tv.o = r.o;
+        tv.d = r.d;
+        tv.inv = inv_dir(r.d);
+    }
+    trav_goto(mem, sc.n_units, tv, next);
 }
 
 template <class R> struct Hit { // hittable.h:10 hit_record
     V3<R> p, n;
     R t, u, v;
     int mat;
-    int kind, idx;
+    int kind, off;
+    int prim; // description node id of the primitive
     bool front;
 };
 
@@ -354,53 +479,97 @@ template <class R> RT_DEV void sphere_uv(V3<R> p, R &u, R &v) { // sphere.h:89
 }
 
 // Re-derive the full hit record of the winning primitive (same arithmetic as the reference's success path).
-template <class R> RT_DEV Hit<R> finalize(const SceneT<R> &sc, const RayT<R> &world, const Best<R> &b, bool want_uv) {
+template <class R, bool ALL_LDS>
+RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const RayT<R> &world, R best_t, int best_off, int best_ctx,
+                       bool want_all) {
     Hit<R> h;
-    h.t = b.t;
-    h.kind = b.meta & 15;
-    h.idx = b.meta >> 4;
+    h.t = best_t;
+    h.off = best_off;
     h.u = R(0);
     h.v = R(0);
-    const RayT<R> r = ray_in_ctx(sc, world, b.ctx);
-    h.p = ray_at(r, b.t);
+    h.prim = -1;
+    const UnitT<R> u0 = mem.ld(best_off), u1 = mem.ld(best_off + 1);
+    const int hdr = ldi(u1.w[3]);
+    h.kind = hdr & 15;
+    const RayT<R> r = ray_in_ctx(sc, world, best_ctx);
+    h.p = ray_at(r, best_t);
     if (h.kind == K_SPHERE) {
-        const SphereT<R> s = sc.spheres[h.idx];
-        V3<R> cc = ld3(s.c) + scale<R>(r.tm, ld3(s.d));
-        V3<R> outward = divide<R>(h.p - cc, s.radius);
+        V3<R> cc = mk<R>(u0.w[0], u0.w[1], u0.w[2]);
+        if (hdr >> 4) {
+            const UnitT<R> u2 = mem.ld(best_off + 2);
+            cc = cc + scale<R>(r.tm, mk<R>(u2.w[0], u2.w[1], u2.w[2]));
+        } else if constexpr (sizeof(R) == 8) {
+            cc = cc + scale<R>(r.tm, mk<R>(R(0), R(0), R(0)));
+        }
+        V3<R> outward = divide<R>(h.p - cc, u0.w[3]);
         h.front = dot(r.d, outward) < R(0);
         h.n = h.front ? outward : -outward;
-        h.mat = s.mat;
-        if (want_uv || sc.mats[s.mat].needs_uv) sphere_uv(outward, h.u, h.v);
-    } else if (h.kind == K_QUAD) {
-        const QuadT<R> q = sc.quads[h.idx];
-        V3<R> ph = h.p - ld3(q.Q);
-        V3<R> w = ld3(q.w);
-        h.u = dot(w, cross(ph, ld3(q.v)));
-        h.v = dot(w, cross(ld3(q.u), ph));
-        V3<R> n = ld3(q.n);
+        h.mat = ldi(u1.w[0]);
+        if (want_all || sc.mats[h.mat].needs_uv) sphere_uv(outward, h.u, h.v);
+        if (want_all) h.prim = ldi(sc.cold[best_off].w[3]);
+    } else if (h.kind == K_AABOX) {
+        // which face: the slab plane whose distance is the winning t
+        const V3<R> inv = inv_dir(r.d);
+        int face = 0;
+        R err = Const<R>::inf;
+        auto probe = [&](R plane, R ro, R ri, int f) {
+            R e = m_abs((plane - ro) * ri - best_t);
+            if (e < err) { err = e; face = f; }
+        };
+        probe(u0.w[0], r.o.x, inv.x, 0);
+        probe(u0.w[3], r.o.x, inv.x, 1);
+        probe(u0.w[1], r.o.y, inv.y, 2);
+        probe(u1.w[0], r.o.y, inv.y, 3);
+        probe(u0.w[2], r.o.z, inv.z, 4);
+        probe(u1.w[1], r.o.z, inv.z, 5);
+        const int axis = face >> 1;
+        const R sgn = (face & 1) ? R(1) : R(-1); // outward direction of this face
+        V3<R> outward = mk<R>(axis == 0 ? sgn : R(0), axis == 1 ? sgn : R(0), axis == 2 ? sgn : R(0));
+        const bool stored_outward = ((hdr >> 4) >> face) & 1;
+        const V3<R> n = stored_outward ? outward : -outward; // the quad's own normal (quad.h:15)
         h.front = dot(r.d, n) < R(0);
         h.n = h.front ? n : -n;
-        h.mat = q.mat;
+        h.mat = ldi(u1.w[2]);
+        if (want_all) {
+            const UnitT<R> c = sc.cold[best_off + (face >> 2)];
+            const int k = face & 3;
+            h.prim = ldi(k == 0 ? c.w[0] : (k == 1 ? c.w[1] : (k == 2 ? c.w[2] : c.w[3])));
+        }
+    } else if (h.kind == K_QUAD) {
+        const UnitT<R> u2 = mem.ld(best_off + 2), u3 = mem.ld(best_off + 3), u4 = mem.ld(best_off + 4);
+        V3<R> ph = h.p - mk<R>(u1.w[0], u1.w[1], u1.w[2]);
+        V3<R> w = mk<R>(u4.w[0], u4.w[1], u4.w[2]);
+        h.u = dot(w, cross(ph, mk<R>(u3.w[0], u3.w[1], u3.w[2])));
+        h.v = dot(w, cross(mk<R>(u2.w[0], u2.w[1], u2.w[2]), ph));
+        V3<R> n = mk<R>(u0.w[0], u0.w[1], u0.w[2]);
+        h.front = dot(r.d, n) < R(0);
+        h.n = h.front ? n : -n;
+        h.mat = ldi(u2.w[3]);
+        if (want_all) h.prim = ldi(sc.cold[best_off].w[3]);
     } else if (h.kind == K_TRI) {
-        const TriT<R> tr = sc.tris[h.idx];
+        const UnitT<R> u2 = mem.ld(best_off + 2);
         R t;
         float u = 0.f, v = 0.f;
-        tri_t(tr, r, -Const<R>::inf, Const<R>::inf, t, u, v);
+        tri_t(mk<R>(u0.w[0], u0.w[1], u0.w[2]), mk<R>(u0.w[3], u1.w[0], u1.w[1]), mk<R>(u1.w[2], u2.w[0], u2.w[1]), ldi(u2.w[3]),
+              r.o, r.d, -Const<R>::inf, Const<R>::inf, t, u, v);
         h.u = R(u);
         h.v = R(v);
-        V3<R> n = ld3(tr.n);
+        const UnitT<R> c = sc.cold[best_off];
+        V3<R> n = mk<R>(c.w[0], c.w[1], c.w[2]);
         h.front = dot(r.d, n) < R(0);
         h.n = h.front ? n : -n;
-        h.mat = tr.mat;
+        h.mat = ldi(u2.w[2]);
+        h.prim = ldi(c.w[3]);
     } else { // K_MEDIUM, constant_medium.h:46-51
         h.n = mk<R>(R(1), R(0), R(0));
         h.front = true;
-        h.mat = sc.media[h.idx].mat;
+        h.mat = ldi(u1.w[1]);
+        h.prim = ldi(u1.w[2]);
     }
-    if (b.ctx != 0) { // leave object space, innermost transform first (hittable.h:62, 135-145)
-        const XformT<R> X = sc.xforms[b.ctx];
-        for (int k = X.depth - 1; k >= 0; k--) {
-            const XformT<R> x = sc.xforms[X.chain[k]];
+    if (best_ctx != 0) { // leave object space, innermost transform first (hittable.h:62, 135-145)
+        const XformT<R> *X = sc.xforms + best_ctx;
+        for (int k = X->depth - 1; k >= 0; k--) {
+            const XformT<R> x = sc.xforms[X->chain[k]];
             if (x.kind == XF_TRANSLATE) {
                 h.p = h.p + mk<R>(x.p[0], x.p[1], x.p[2]);
             } else {
@@ -631,18 +800,16 @@ template <class R> RT_DEV RayT<R> get_ray(const CameraT<R> &cam, int i, int j, i
     return r;
 }
 
-// One bounce of camera::ray_color (camera.h:291-326), written iteratively: radiance L += beta * (emitted | background),
-// beta *= attenuation * scattering_pdf / pdf.  Returns false when the path ends.
-template <class R>
-RT_DEV bool bounce(const SceneT<R> &sc, const CameraT<R> &cam, RayT<R> &ray, V3<R> &beta, V3<R> &L, Rng<R> &g, int bounce_idx) {
-    auto mxi = [&](int node_id) { return g.medium(node_id, bounce_idx); };
-    Best<R> b = traverse(sc, ray, R(0.001), Const<R>::inf, mxi);
-    if (b.meta < 0) { // camera.h:300
+// The part of camera::ray_color (camera.h:291-326) that follows world.hit(), written iteratively: radiance
+// L += beta * (emitted | background), beta *= attenuation * scattering_pdf / pdf.  Returns false when the path ends.
+template <class R, bool ALL_LDS>
+RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const CameraT<R> &cam, RayT<R> &ray, R best_t, int best_off,
+                  int best_ctx, V3<R> &beta, V3<R> &L, Rng<R> &g) {
+    if (best_off < 0) { // camera.h:300
         L = L + beta * ld3(cam.background);
         return false;
     }
-    // which material? (needed before finalize to know whether u,v matter)
-    Hit<R> h = finalize(sc, ray, b, false);
+    Hit<R> h = finalize(mem, sc, ray, best_t, best_off, best_ctx, false);
     const MatT<R> m = sc.mats[h.mat];
     V3<R> emitted = mk<R>(R(0), R(0), R(0));
     if (m.kind == RT_MAT_DIFFUSE_LIGHT) { // material.h:129
@@ -700,17 +867,13 @@ RT_DEV bool bounce(const SceneT<R> &sc, const CameraT<R> &cam, RayT<R> &ray, V3<
     }
     R pdf_value = R(0.5) * v0 + R(0.5) * v1;
     R wgt = spdf / pdf_value;
-#ifdef RT_DEBUG_NAN
-    if (wgt != wgt || atten.x != atten.x)
-        printf("NAN diffuse: bounce %d mat %d kind %d v0 %g v1 %g spdf %g dir %g %g %g n %g %g %g p %g %g %g atten %g t %g primkind %d\n", bounce_idx,
-               h.mat, m.kind, (double)v0, (double)v1, (double)spdf, (double)dir.x, (double)dir.y, (double)dir.z, (double)h.n.x,
-               (double)h.n.y, (double)h.n.z, (double)h.p.x, (double)h.p.y, (double)h.p.z, (double)atten.x, (double)h.t, h.kind);
-#endif
     beta = beta * scale<R>(wgt, atten);
     ray.o = h.p;
     ray.d = dir;
     return true;
 }
+
+template <class R> struct Accum { typedef R type; };
 
 struct RenderArgs {
     uint32_t k0, k1;
@@ -718,78 +881,126 @@ struct RenderArgs {
     int32_t chunk_size;
     int32_t tiles_x, tiles_y;
     int32_t n_chunks;
+    int32_t leaf_threshold;  // run the leaf code once this many lanes wait at a non-BOX record
+    int32_t shade_threshold; // run the shading code once this many lanes have finished their traversal
 };
 
-// One wave = one 8x8 pixel tile x one chunk of the stratified sample range.  Each lane owns a pixel and runs its
-// samples back to back ("path regeneration"): the loop body is one bounce of whichever path the lane is on, so
-// lanes whose path ended start their next sample instead of idling until the longest path of the wave finishes.
-template <class R>
-__global__ void __launch_bounds__(256) render_kernel(SceneT<R> sc, CameraT<R> cam, RenderArgs a, float *__restrict__ out,
-                                                     unsigned long long *__restrict__ ray_counter) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + wave;
-    if (tile >= a.tiles_x * a.tiles_y) return;
-    const int chunk = blockIdx.y;
-    const int ti = tile % a.tiles_x, tj = tile / a.tiles_x;
-    const int i = ti * 8 + (lane & 7), j = tj * 8 + (lane >> 3);
-    const bool inside = (i < cam.W) && (j < cam.H);
-    int s = a.s_begin + chunk * a.chunk_size;
-    int s_end = s + a.chunk_size;
-    if (s_end > a.s_end) s_end = a.s_end;
-    if (!inside) s = s_end;
-
+// Persistent megakernel.  A workgroup stages the scene stream into LDS once, then each of its waves pulls work items
+// (8x8 pixel tile x chunk of the stratified sample range) from a global cursor.  Inside an item every lane owns a pixel
+// and runs its samples back to back (path regeneration).  The wave is a three-state machine: at any time a lane is at
+// a BOX record, at a leaf record, or waiting to be shaded; each trip of the loop runs ONE of the three code blocks,
+// chosen wave-uniformly, so the hot BOX step is never serialised behind leaf or shading code that only a few lanes
+// need (64-lane divergence is the limiter of this workload: see DESIGN.md, profiles/).
+template <class R, bool ALL_LDS, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc, CameraT<R> cam, RenderArgs a, float *__restrict__ out,
+                                                       unsigned long long *__restrict__ counters) {
+    stage_stream(sc);
+    const Mem<R, ALL_LDS> mem{sc.stream, sc.lds_units};
+    const int lane = threadIdx.x & 63;
+    const int n_tiles = a.tiles_x * a.tiles_y;
+    const int n_items = n_tiles * a.n_chunks;
+    const int n_units = sc.n_units;
+    const R tmin = R(0.001);
+    unsigned rays = 0;
     Rng<R> g;
     g.k0 = a.k0;
     g.k1 = a.k1;
     g.have = 0;
-    const uint32_t pixel = (uint32_t)(j * cam.W + i);
-    double ax = 0, ay = 0, az = 0; // per-pixel sum over samples (the reference sums in double: camera.h:175-181)
-    unsigned rays = 0;
-    RayT<R> ray;
-    V3<R> beta, L;
-    int depth = 0; // remaining ray_color depth; 0 = need a new camera path
-    bool active = false;
-    while (true) {
-        if (!active) {
-            if (s >= s_end) break;
-            g.begin(pixel, (uint32_t)s);
-            ray = get_ray(cam, i, j, s % cam.sqrt_spp, s / cam.sqrt_spp, g);
-            beta = mk<R>(R(1), R(1), R(1));
-            L = mk<R>(R(0), R(0), R(0));
-            depth = cam.max_depth;
-            active = true;
-        }
-        bool alive = false;
-        if (depth > 0) { // camera.h:294
-            rays++;
-    #ifdef RT_DEBUG_NAN
-            bool was_ok = !(beta.x != beta.x) && !(ray.d.x != ray.d.x) && !(L.x != L.x);
-#endif
-            alive = bounce(sc, cam, ray, beta, L, g, cam.max_depth - depth);
-#ifdef RT_DEBUG_NAN
-            if (was_ok && ((beta.x != beta.x) || (ray.d.x != ray.d.x) || (ray.o.x != ray.o.x) || (L.x != L.x)))
-                printf("NAN after bounce %d: beta %g dir %g %g %g o %g %g %g L %g alive %d\n", cam.max_depth - depth, (double)beta.x,
-                       (double)ray.d.x, (double)ray.d.y, (double)ray.d.z, (double)ray.o.x, (double)ray.o.y, (double)ray.o.z, (double)L.x, (int)alive);
-#endif
-            depth--;
-            if (alive && depth == 0) { // depth exhausted: the recursion returns 0 here (camera.h:294-295)
-                L = L + beta * mk<R>(R(0), R(0), R(0));
-                alive = false;
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = (int)atomicAdd(&counters[1], 1ull);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        const int chunk = item / n_tiles, tile = item - chunk * n_tiles;
+        const int tj = tile / a.tiles_x, ti = tile - tj * a.tiles_x;
+        const int i = ti * 8 + (lane & 7), j = tj * 8 + (lane >> 3);
+        const bool inside = (i < cam.W) && (j < cam.H);
+        int s = a.s_begin + chunk * a.chunk_size;
+        int s_end = s + a.chunk_size;
+        if (s_end > a.s_end) s_end = a.s_end;
+        if (!inside) s = s_end;
+        const uint32_t pixel = (uint32_t)(j * cam.W + i);
+        // per-pixel sum over the samples of this item (<= a few hundred; the reference sums in double: camera.h:175-181;
+        // the float path sums an item in float and the items of a pixel in double, reduce_chunks_kernel)
+        typename Accum<R>::type ax = 0, ay = 0, az = 0;
+        RayT<R> ray;
+        V3<R> beta, L;
+        Trav<R> tv;
+        tv.i = n_units;
+        tv.hdr = 0;
+        int depth = 0;
+        bool have_path = false;
+
+        // start the next camera path of this lane (or retire the lane)
+        auto next_path = [&]() {
+            have_path = false;
+            while (s < s_end) {
+                g.begin(pixel, (uint32_t)s);
+                ray = get_ray(cam, i, j, s % cam.sqrt_spp, s / cam.sqrt_spp, g);
+                beta = mk<R>(R(1), R(1), R(1));
+                L = mk<R>(R(0), R(0), R(0));
+                depth = cam.max_depth;
+                if (depth > 0) { // camera.h:294
+                    rays++;
+                    trav_begin(mem, n_units, tv, ray);
+                    have_path = true;
+                    return;
+                }
+                s++; // max_depth <= 0: the sample is black
+            }
+            tv.i = n_units;
+        };
+        next_path();
+
+        for (;;) {
+            const bool trav = have_path && tv.i < n_units;
+            const bool is_box = trav && (tv.hdr & 15) == K_BOX;
+            const bool is_leaf = trav && !is_box;
+            const bool ready = have_path && !trav;
+            const unsigned long long mb = __ballot(is_box), ml = __ballot(is_leaf), mr = __ballot(ready);
+            if (!(mb | ml | mr)) break;
+            const int nl = __popcll(ml), nr = __popcll(mr);
+            int action; // 0 box, 1 leaf, 2 shade
+            if (nr >= a.shade_threshold) action = 2;
+            else if (nl >= a.leaf_threshold) action = 1;
+            else if (mb) action = 0;
+            else if (ml) action = 1;
+            else action = 2;
+            if (action == 0) {
+                if (is_box) trav_box_step(mem, n_units, tv, tmin);
+            } else if (action == 1) {
+                if (is_leaf) {
+                    const int bounce_idx = cam.max_depth - depth;
+                    auto mxi = [&](int node_id) { return g.medium(node_id, bounce_idx); };
+                    trav_leaf_step(mem, sc, tv, ray, tmin, mxi);
+                }
+            } else {
+                if (ready) {
+                    bool alive = shade(mem, sc, cam, ray, tv.best_t, tv.best_off, tv.best_ctx, beta, L, g);
+                    depth--;
+                    if (alive && depth == 0) { // depth exhausted: the recursion returns 0 here (camera.h:294-295)
+                        L = L + beta * mk<R>(R(0), R(0), R(0));
+                        alive = false;
+                    }
+                    if (alive) {
+                        rays++;
+                        trav_begin(mem, n_units, tv, ray);
+                    } else {
+                        ax += L.x; ay += L.y; az += L.z;
+                        s++;
+                        next_path();
+                    }
+                }
             }
         }
-        if (!alive) {
-            ax += (double)L.x; ay += (double)L.y; az += (double)L.z;
-            s++;
-            active = false;
+        if (inside) {
+            size_t o = ((size_t)chunk * cam.H * cam.W + (size_t)j * cam.W + i) * 3;
+            out[o] = (float)ax; out[o + 1] = (float)ay; out[o + 2] = (float)az;
         }
-    }
-    if (inside) {
-        size_t o = ((size_t)chunk * cam.H * cam.W + (size_t)j * cam.W + i) * 3;
-        out[o] = (float)ax; out[o + 1] = (float)ay; out[o + 2] = (float)az;
     }
     // wave-level ray count -> one atomic per wave
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_xor(rays, off);
-    if (lane == 0 && ray_counter) atomicAdd(ray_counter, (unsigned long long)rays);
+    if (lane == 0) atomicAdd(&counters[0], (unsigned long long)rays);
 }
 
 struct TraceArgs {
@@ -798,46 +1009,48 @@ struct TraceArgs {
 };
 
 // rt_trace_batch: closest hit of each ray over [0.001, inf) (camera.h:300).
-template <class R>
-__global__ void __launch_bounds__(256) trace_kernel(SceneT<R> sc, const rt_ray *__restrict__ rays, const double *__restrict__ xi, size_t n,
-                                                    rt_hit *__restrict__ out, TraceArgs a) {
-    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    RayT<R> r;
-    r.o = mk<R>(R(rays[k].orig[0]), R(rays[k].orig[1]), R(rays[k].orig[2]));
-    r.d = mk<R>(R(rays[k].dir[0]), R(rays[k].dir[1]), R(rays[k].dir[2]));
-    r.tm = R(rays[k].time);
-    const R xik = a.has_xi ? R(xi[k]) : R(0);
-    auto mxi = [&](int node_id) {
-        if (a.has_xi) return xik;
-        uint32_t o0, o1, o2, o3;
-        philox4x32_10((uint32_t)node_id, (uint32_t)k, (uint32_t)((uint64_t)k >> 32), 0x7fffffffu, a.k0, a.k1, o0, o1, o2, o3);
-        return u01<R>(o0);
-    };
-    Best<R> b = traverse(sc, r, R(0.001), Const<R>::inf, mxi);
-    rt_hit o;
-    o.prim = -1;
-    o.front_face = 0;
-    o.t = (double)Const<double>::inf;
-    o.p[0] = o.p[1] = o.p[2] = 0;
-    o.normal[0] = o.normal[1] = o.normal[2] = 0;
-    o.u = o.v = 0;
-    if (b.meta >= 0) {
-        Hit<R> h = finalize(sc, r, b, true);
-        int id;
-        if (h.kind == K_SPHERE) id = sc.sphere_ids[h.idx];
-        else if (h.kind == K_QUAD) id = sc.quad_ids[h.idx];
-        else if (h.kind == K_TRI) id = sc.tri_ids[h.idx];
-        else id = sc.media[h.idx].node_id;
-        o.prim = id;
-        o.front_face = h.front ? 1 : 0;
-        o.t = (double)h.t;
-        o.p[0] = h.p.x; o.p[1] = h.p.y; o.p[2] = h.p.z;
-        o.normal[0] = h.n.x; o.normal[1] = h.n.y; o.normal[2] = h.n.z;
-        o.u = (double)h.u;
-        o.v = (double)h.v;
+template <class R, bool ALL_LDS, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) trace_kernel(SceneT<R> sc, const rt_ray *__restrict__ rays, const double *__restrict__ xi,
+                                                      size_t n, rt_hit *__restrict__ out, TraceArgs a) {
+    stage_stream(sc);
+    const Mem<R, ALL_LDS> mem{sc.stream, sc.lds_units};
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+        RayT<R> r;
+        r.o = mk<R>(R(rays[k].orig[0]), R(rays[k].orig[1]), R(rays[k].orig[2]));
+        r.d = mk<R>(R(rays[k].dir[0]), R(rays[k].dir[1]), R(rays[k].dir[2]));
+        r.tm = R(rays[k].time);
+        const R xik = a.has_xi ? R(xi[k]) : R(0);
+        auto mxi = [&](int node_id) {
+            if (a.has_xi) return xik;
+            uint32_t o0, o1, o2, o3;
+            philox4x32_10((uint32_t)node_id, (uint32_t)k, (uint32_t)((uint64_t)k >> 32), 0x7fffffffu, a.k0, a.k1, o0, o1, o2, o3);
+            return u01<R>(o0);
+        };
+        Trav<R> tv;
+        trav_begin(mem, sc.n_units, tv, r);
+        while (tv.i < sc.n_units) {
+            if ((tv.hdr & 15) == K_BOX) trav_box_step(mem, sc.n_units, tv, R(0.001));
+            else trav_leaf_step(mem, sc, tv, r, R(0.001), mxi);
+        }
+        rt_hit o;
+        o.prim = -1;
+        o.front_face = 0;
+        o.t = (double)Const<double>::inf;
+        o.p[0] = o.p[1] = o.p[2] = 0;
+        o.normal[0] = o.normal[1] = o.normal[2] = 0;
+        o.u = o.v = 0;
+        if (tv.best_off >= 0) {
+            Hit<R> h = finalize(mem, sc, r, tv.best_t, tv.best_off, tv.best_ctx, true);
+            o.prim = h.prim;
+            o.front_face = h.front ? 1 : 0;
+            o.t = (double)h.t;
+            o.p[0] = h.p.x; o.p[1] = h.p.y; o.p[2] = h.p.z;
+            o.normal[0] = h.n.x; o.normal[1] = h.n.y; o.normal[2] = h.n.z;
+            o.u = (double)h.u;
+            o.v = (double)h.v;
+        }
+        out[k] = o;
     }
-    out[k] = o;
 }
 
 } // namespace rtamd

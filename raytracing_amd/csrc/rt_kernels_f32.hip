@@ -27,7 +27,7 @@ __global__ void tonemap_kernel(const float *__restrict__ accum, double scale, si
 template hipError_t launch_render<float>(const SceneT<float> &, const CameraT<float> &, const RenderLaunch &, float *,
                                          unsigned long long *, hipStream_t);
 template hipError_t launch_trace<float>(const SceneT<float> &, const rt_ray *, const double *, size_t, rt_hit *, uint32_t,
-                                        uint32_t, hipStream_t);
+                                        uint32_t, int, hipStream_t);
 
 hipError_t launch_reduce_chunks(const float *partial, float *out, size_t n, int n_chunks, hipStream_t stream) {
     if (n == 0) return hipSuccess;

@@ -7,6 +7,6 @@ namespace rtamd {
 template hipError_t launch_render<double>(const SceneT<double> &, const CameraT<double> &, const RenderLaunch &, float *,
                                           unsigned long long *, hipStream_t);
 template hipError_t launch_trace<double>(const SceneT<double> &, const rt_ray *, const double *, size_t, rt_hit *, uint32_t,
-                                         uint32_t, hipStream_t);
+                                         uint32_t, int, hipStream_t);
 
 } // namespace rtamd

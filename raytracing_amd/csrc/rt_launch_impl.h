@@ -6,9 +6,15 @@
 
 namespace rtamd {
 
+// A kernel that asks for more than 64 KiB of dynamic LDS must say so once.
+template <class K> hipError_t allow_lds(K kernel, int bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
 template <class R>
 hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const RenderLaunch &rl, float *out,
-                         unsigned long long *ray_counter, hipStream_t stream) {
+                         unsigned long long *counters, hipStream_t stream) {
+    using C = LaunchCfg<R>;
     RenderArgs a;
     a.k0 = rl.k0;
     a.k1 = rl.k1;
@@ -18,22 +24,53 @@ hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const Rende
     a.n_chunks = rl.n_chunks;
     a.tiles_x = (cam.W + 7) / 8;
     a.tiles_y = (cam.H + 7) / 8;
-    const int tiles = a.tiles_x * a.tiles_y;
-    dim3 grid((tiles + 3) / 4, rl.n_chunks, 1), block(256, 1, 1);
-    hipLaunchKernelGGL(render_kernel<R>, grid, block, 0, stream, sc, cam, a, out, ray_counter);
+    a.leaf_threshold = rl.leaf_threshold < 1 ? 1 : rl.leaf_threshold;
+    a.shade_threshold = rl.shade_threshold < 1 ? 1 : rl.shade_threshold;
+    if (sc.lds_units < 0 || sc.lds_units > sc.n_units || (size_t)sc.lds_units * sizeof(UnitT<R>) > (size_t)C::lds_bytes)
+        return hipErrorInvalidValue;
+    const size_t lds = (size_t)sc.lds_units * sizeof(UnitT<R>);
+    const long long items = (long long)a.tiles_x * a.tiles_y * rl.n_chunks;
+    const int waves_per_block = C::block / 64;
+    long long want = (items + waves_per_block - 1) / waves_per_block;
+    long long cap = (long long)rl.n_cus * C::blocks_per_cu;
+    dim3 grid((unsigned)(want < cap ? (want < 1 ? 1 : want) : cap), 1, 1), block(C::block, 1, 1);
+    hipError_t e;
+    if (sc.lds_units == sc.n_units) {
+        auto k = render_kernel<R, true, C::block>;
+        if ((e = allow_lds(k, C::lds_bytes)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, block, lds, stream, sc, cam, a, out, counters);
+    } else {
+        auto k = render_kernel<R, false, C::block>;
+        if ((e = allow_lds(k, C::lds_bytes)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, block, lds, stream, sc, cam, a, out, counters);
+    }
     return hipGetLastError();
 }
 
 template <class R>
 hipError_t launch_trace(const SceneT<R> &sc, const rt_ray *d_rays, const double *d_xi, size_t n, rt_hit *d_out,
-                        uint32_t k0, uint32_t k1, hipStream_t stream) {
+                        uint32_t k0, uint32_t k1, int n_cus, hipStream_t stream) {
+    using C = LaunchCfg<R>;
     if (n == 0) return hipSuccess;
     TraceArgs a;
     a.k0 = k0;
     a.k1 = k1;
     a.has_xi = d_xi != nullptr;
-    dim3 grid((unsigned)((n + 255) / 256), 1, 1), block(256, 1, 1);
-    hipLaunchKernelGGL(trace_kernel<R>, grid, block, 0, stream, sc, d_rays, d_xi, n, d_out, a);
+    if (sc.lds_units < 0 || sc.lds_units > sc.n_units || (size_t)sc.lds_units * sizeof(UnitT<R>) > (size_t)C::lds_bytes)
+        return hipErrorInvalidValue;
+    const size_t lds = (size_t)sc.lds_units * sizeof(UnitT<R>);
+    size_t want = (n + C::block - 1) / C::block, cap = (size_t)n_cus * C::blocks_per_cu;
+    dim3 grid((unsigned)(want < cap ? want : cap), 1, 1), block(C::block, 1, 1);
+    hipError_t e;
+    if (sc.lds_units == sc.n_units) {
+        auto k = trace_kernel<R, true, C::block>;
+        if ((e = allow_lds(k, C::lds_bytes)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, block, lds, stream, sc, d_rays, d_xi, n, d_out, a);
+    } else {
+        auto k = trace_kernel<R, false, C::block>;
+        if ((e = allow_lds(k, C::lds_bytes)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, block, lds, stream, sc, d_rays, d_xi, n, d_out, a);
+    }
     return hipGetLastError();
 }
 

@@ -1,22 +1,37 @@
-// rt_scene.h -- device-resident scene layout (HBM) of the gfx950 path tracer, templated on the arithmetic type.
+// rt_scene.h -- device-resident scene layout of the gfx950 path tracer, templated on the arithmetic type.
 //
 // The reference's object graph (bvh_node / hittable_list / translate / rotate_y / constant_medium / primitives,
-// src/cpu/*.h) is flattened on the host into ONE linear "threaded" node array in depth-first pre-order -- exactly
+// src/cpu/*.h) is flattened on the host into ONE linear "threaded" record stream in depth-first pre-order -- exactly
 // the order in which the reference's recursion visits objects (bvh.h:43-51 left then right, hittable_list.h:29
-// insertion order).  Each node carries a skip link, so traversal needs no stack at all and reproduces the
+// insertion order).  Box records carry a skip link, so traversal needs no stack at all and reproduces the
 // reference's closest-hit tie-breaking (strict vs inclusive interval tests, sphere.h:44 / quad.h:41) by construction.
 //
-//   node i:  kind BOX      -> slab test (aabb.h:36); hit: i+1, miss: skip
-//            kind SPHERE.. -> primitive test against [tmin, closest so far]; next: i+1
-//            kind XF_ENTER -> transform the ray into object space (hittable.h:55,114); next: i+1
-//            kind XF_EXIT  -> restore the parent space's ray; next: i+1
+// The stream is an array of UNITS of four scalars (f32: 16 B = one ds_read_b128 / global_load_dwordx4, f64: 32 B).
+// Primitives are stored inline in the stream (no second dependent fetch), every record is >= 2 units and keeps its
+// header (kind | payload << 4) in the last scalar of its second unit, so one traversal step always starts with the
+// same two unit loads.  The leading `lds_units` units of the stream are staged into the CU's LDS (160 KiB) by every
+// workgroup; the remainder (large meshes) is read from global memory through L1/L2.
 //
-// Records are arrays of 16-byte-multiple structs: every lane gathers a different node / primitive, so the unit of
-// locality is the record (1-5 dwordx4 loads from one or two cache lines), not a column.
+//   record            units  unit0                     unit1                              unit2..
+//   BOX     (bvh_node)   2   bmin.xyz, bmax.x          bmax.y, bmax.z, skip, hdr
+//   SPHERE               2/3 c.xyz, radius             mat, -, -, hdr(payload bit0=moving)  d.xyz (moving: centre = c + time*d)
+//   AABOX   (box())      2   bmin.xyz, bmax.x          bmax.y, bmax.z, mat, hdr(payload = 6 face-orientation bits)
+//   QUAD                 5   n.xyz, D                  Q.xyz, hdr                         u.xyz, mat | v.xyz, area | w.xyz, -
+//   TRI                  3   v0.xyz, e1.x              e1.y, e1.z, e2.x, hdr              e2.y, e2.z, mat, cull
+//   MEDIUM               2   c.xyz, radius (boundary)  -1/density, mat, node_id, hdr
+//   XF_ENTER             2   p0, p1, p2, -             xf kind, ctx id, -, hdr            (translate: offset; rotate_y: sin, cos)
+//   XF_EXIT              2   -                         -, parent ctx id, -, hdr
+//
+// AABOX exists in the f32 stream only: a hittable_list of six axis-aligned quads that form a closed box with one
+// material (what box() of quad.h:103 builds) is fused into one slab test.  The f64 parity stream keeps the six quads.
+//
+// `cold` is a parallel array (same unit offsets) that only hit finalisation and rt_trace_batch read:
+// cold[off] = { triangle normal xyz | 0, description node id }.
 #ifndef RT_SCENE_H
 #define RT_SCENE_H
 
 #include <stdint.h>
+#include <string.h>
 
 namespace rtamd {
 
@@ -28,54 +43,46 @@ enum : int {
     K_MEDIUM = 4,
     K_XF_ENTER = 5,
     K_XF_EXIT = 6,
+    K_AABOX = 7,
 };
 enum : int { XF_TRANSLATE = 0, XF_ROTATE_Y = 1 };
 enum : int { MAX_XF_DEPTH = 4 };
 enum : int { LIGHT_OTHER = 0, LIGHT_SPHERE = 1, LIGHT_QUAD = 2 };
 
-inline int make_meta(int kind, int index) { return (index << 4) | kind; }
-
-template <class R> struct alignas(16) NodeT { // f32: 32 B, f64: 64 B
-    R bmin[3];
-    R bmax[3];
-    int32_t skip;
-    int32_t meta; // kind | index<<4
+template <class R> struct alignas(4 * sizeof(R)) UnitT {
+    R w[4];
 };
 
-template <class R> struct alignas(16) SphereT { // f32: 32 B, f64: 64 B
-    R c[3];
-    R radius;
-    R d[3]; // centre velocity (moving sphere: centre = c + time*d, sphere.h:30)
-    int32_t mat;
-};
-
-template <class R> struct alignas(16) QuadT { // f32: 80 B, f64: 144 B
-    R n[3];
-    R D;
-    R Q[3];
-    R area;
-    R u[3];
-    R v[3];
-    R w[3];
-    int32_t mat;
-};
-
-template <class R> struct alignas(16) TriT { // f32: 64 B, f64: 112 B
-    R v0[3];
-    R v1[3];
-    R v2[3];
-    R n[3];
-    int32_t mat;
-    int32_t cull;
-};
-
-template <class R> struct alignas(16) MediumT {
-    R neg_inv_density;
-    int32_t sphere; // boundary (index into spheres)
-    int32_t mat;
-    int32_t node_id; // key of the medium's RNG draw
-    int32_t pad_;
-};
+// integers live in scalar slots by bit pattern (never touched by arithmetic)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_HD __host__ __device__ __forceinline__
+#elif defined(__HIPCC__)
+#define RT_HD __host__ __device__ inline
+#else
+#define RT_HD inline
+#endif
+RT_HD float enc_int(int32_t v, float) {
+    float f;
+    __builtin_memcpy(&f, &v, 4);
+    return f;
+}
+RT_HD double enc_int(int32_t v, double) {
+    int64_t x = v;
+    double f;
+    __builtin_memcpy(&f, &x, 8);
+    return f;
+}
+RT_HD int32_t dec_int(float f) {
+    int32_t v;
+    __builtin_memcpy(&v, &f, 4);
+    return v;
+}
+RT_HD int32_t dec_int(double f) {
+    int64_t v;
+    __builtin_memcpy(&v, &f, 8);
+    return (int32_t)v;
+}
+RT_HD int make_hdr(int kind, int payload) { return (payload << 4) | kind; }
 
 template <class R> struct alignas(16) XformT {
     int32_t kind;
@@ -116,6 +123,24 @@ template <class R> struct PerlinT {
     int32_t perm_x[256], perm_y[256], perm_z[256];
 };
 
+template <class R> struct SphereT { // light shapes only (world spheres live in the stream)
+    R c[3];
+    R radius;
+    R d[3];
+    int32_t mat;
+};
+
+template <class R> struct QuadT { // light shapes only
+    R n[3];
+    R D;
+    R Q[3];
+    R area;
+    R u[3];
+    R v[3];
+    R w[3];
+    int32_t mat;
+};
+
 template <class R> struct alignas(16) LightT {
     int32_t kind;
     int32_t pad_[3];
@@ -137,11 +162,8 @@ template <class R> struct CameraT {
 };
 
 template <class R> struct SceneT { // device pointers; passed to kernels by value
-    const NodeT<R> *nodes;
-    const SphereT<R> *spheres;
-    const QuadT<R> *quads;
-    const TriT<R> *tris;
-    const MediumT<R> *media;
+    const UnitT<R> *stream;
+    const UnitT<R> *cold;
     const XformT<R> *xforms;
     const MatT<R> *mats;
     const TexT<R> *texs;
@@ -149,13 +171,10 @@ template <class R> struct SceneT { // device pointers; passed to kernels by valu
     const uint8_t *image_bytes;
     const PerlinT<R> *perlins;
     const LightT<R> *lights;
-    const int32_t *sphere_ids; // table index -> description node id (prim id reported by rt_trace_batch)
-    const int32_t *quad_ids;
-    const int32_t *tri_ids;
-    int32_t n_nodes;
+    int32_t n_units;
+    int32_t lds_units; // leading units of `stream` that the kernels stage into LDS
     int32_t n_lights;
     int32_t lights_is_list; // lights_root is a hittable_list (hittable_list.h:52 draws the pick) vs a bare shape
-    int32_t pad_;
 };
 
 } // namespace rtamd
