@@ -110,7 +110,9 @@ struct Ctx {
     const rt_scene_desc *sc;
     int mode;
     // philox state
-    uint32_t k0 = 0, k1 = 0, pixel = 0, sample = 0, block = 0, have = 0;
+    // counter = (block, sample, pixel, stream): stream 0 = the camera ray's draws (get_ray), 0x80000000|b = the draws of
+    // ray_color invocation b of the path (scatter + mixture pdf), 1+b = constant_medium draws (keyed by node id)
+    uint32_t k0 = 0, k1 = 0, pixel = 0, sample = 0, block = 0, have = 0, stream = 0;
     uint32_t buf[4];
     int bounce = 0;
     double inject = 0; // RNG_INJECT: every draw returns this
@@ -118,13 +120,14 @@ struct Ctx {
     bool trace_keyed = false; // rt_trace_batch with xi == NULL
     Counters cnt;
 
-    void begin_sample(uint32_t px, uint32_t s) { pixel = px; sample = s; block = 0; have = 0; }
+    void begin_sample(uint32_t px, uint32_t s) { pixel = px; sample = s; block = 0; have = 0; stream = 0; }
+    void begin_bounce(int b) { block = 0; have = 0; stream = 0x80000000u | (uint32_t)b; }
 
     double next() { // utils.h:33 random_double()
         if (mode == RNG_GLIBC) return std::rand() / (RAND_MAX + 1.0);
         if (mode == RNG_INJECT) return inject;
         if (have == 0) {
-            philox4x32_10(block++, sample, pixel, 0, k0, k1, buf);
+            philox4x32_10(block++, sample, pixel, stream, k0, k1, buf);
             have = 4;
         }
         uint32_t x = buf[4 - have];
@@ -632,6 +635,7 @@ V ray_color(const Cam &cam, const Ray &r, int depth, Ctx &c) { // camera.h:291
     if (depth <= 0) return mk(0, 0, 0);
     c.cnt.rays++;
     c.bounce = cam.c->max_depth - depth;
+    c.begin_bounce(c.bounce);
     Rec rec;
     if (!node_hit(sc->world_root, r, Interval{0.001, infinity}, rec, c)) return mk(cam.c->background);
     Srec srec;

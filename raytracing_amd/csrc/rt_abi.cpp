@@ -85,9 +85,12 @@ template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, Device
     if (rc) return set_err(ctx, rc, err);
     BlobBuilder b;
     size_t o_stream = b.add(f.stream), o_cold = b.add(f.cold);
+    size_t o_bytes = b.add_bytes(desc->image_bytes, (size_t)desc->n_image_bytes);
+    // the shading tables: one contiguous range (staged into LDS as a whole when it fits)
     size_t o_xf = b.add(f.xforms), o_mats = b.add(f.mats), o_texs = b.add(f.texs);
-    size_t o_img = b.add(f.images), o_bytes = b.add_bytes(desc->image_bytes, (size_t)desc->n_image_bytes);
-    size_t o_perlin = b.add(f.perlins), o_lights = b.add(f.lights);
+    size_t o_img = b.add(f.images), o_perlin = b.add(f.perlins), o_lights = b.add(f.lights);
+    b.host.resize((b.host.size() + 255) & ~size_t(255));
+    const size_t tab_bytes = b.host.size() - o_xf;
     ds.bytes = b.host.size();
     HIP_TRY(ctx, hipMalloc(&ds.blob, ds.bytes));
     HIP_TRY(ctx, hipMemcpy(ds.blob, b.host.data(), ds.bytes, hipMemcpyHostToDevice));
@@ -106,6 +109,10 @@ template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, Device
     int cap = LaunchCfg<R>::lds_bytes / (int)sizeof(UnitT<R>);
     if (ctx->lds_limit_units >= 0 && ctx->lds_limit_units < cap) cap = ctx->lds_limit_units;
     s.lds_units = s.n_units < cap ? s.n_units : cap;
+    s.tab = base + o_xf;
+    s.tab_bytes = (int32_t)tab_bytes;
+    s.tab_in_lds = (s.lds_units == s.n_units && ctx->lds_limit_units < 0 &&
+                    (size_t)s.n_units * sizeof(UnitT<R>) + tab_bytes <= (size_t)LaunchCfg<R>::lds_bytes) ? 1 : 0;
     s.n_lights = (int)f.lights.size();
     s.lights_is_list = f.lights_is_list;
     ds.n_fused_boxes = f.n_fused_boxes;
@@ -180,7 +187,7 @@ int rt_init(int device, rt_ctx **out) {
         delete ctx;
         return RT_ERR_HIP;
     }
-    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&ctx->counter, 2 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&ctx->counter, 16 * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx;
         return RT_ERR_HIP;
@@ -325,7 +332,7 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
     rl.n_cus = ctx->n_cus;
     rl.leaf_threshold = ctx->leaf_threshold > 0 ? ctx->leaf_threshold : 16;
     rl.shade_threshold = ctx->shade_threshold > 0 ? ctx->shade_threshold : 16;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->counter, 0, 2 * sizeof(unsigned long long), stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counter, 0, 16 * sizeof(unsigned long long), stream));
     if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     if (params->precision == RT_PREC_F64)
         HIP_TRY(ctx, launch_render<double>(scene->f64.sc, convert_camera<double>(*cam), rl, target, ctx->counter, stream));
@@ -339,6 +346,16 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         unsigned long long rays = 0;
         HIP_TRY(ctx, hipMemcpy(&rays, ctx->counter, sizeof(rays), hipMemcpyDeviceToHost));
+        if (std::getenv("RT_AMD_PROFILE_ACTIONS")) { // diagnostic builds (-DRT_PROFILE_ACTIONS) fill counters[4..13]
+            unsigned long long c[16];
+            HIP_TRY(ctx, hipMemcpy(c, ctx->counter, sizeof(c), hipMemcpyDeviceToHost));
+            const char *nm[3] = {"box", "leaf", "shade"};
+            for (int k = 0; k < 3; k++)
+                std::fprintf(stderr, "[rt_amd profile] %-5s cycles %.4g (%.1f%% of wave time) trips %.4g cyc/trip %.1f lanes/trip %.1f\n",
+                             nm[k], (double)c[4 + 3 * k], 100.0 * (double)c[4 + 3 * k] / (double)(c[13] ? c[13] : 1), (double)c[5 + 3 * k],
+                             (double)c[4 + 3 * k] / (double)(c[5 + 3 * k] ? c[5 + 3 * k] : 1),
+                             (double)c[6 + 3 * k] / (double)(c[5 + 3 * k] ? c[5 + 3 * k] : 1));
+        }
         stats->samples = (uint64_t)n_px * (uint64_t)n_samples;
         stats->rays = rays;
         stats->kernel_ms = ms;

@@ -34,7 +34,7 @@ RT_DEV float m_acos(float x) { return acosf(x); }
 RT_DEV double m_acos(double x) { return acos(x); }
 RT_DEV float m_atan2(float y, float x) { return atan2f(y, x); }
 RT_DEV double m_atan2(double y, double x) { return atan2(y, x); }
-RT_DEV float m_log(float x) { return logf(x); }
+RT_DEV float m_log(float x) { return __logf(x); } // v_log_f32: ~1e-6 relative on (0,1), enough for a free-path length
 RT_DEV double m_log(double x) { return log(x); }
 RT_DEV float m_floor(float x) { return floorf(x); }
 RT_DEV double m_floor(double x) { return floor(x); }
@@ -46,6 +46,22 @@ RT_DEV float m_max(float a, float b) { return fmaxf(a, b); }
 RT_DEV double m_max(double a, double b) { return fmax(a, b); }
 RT_DEV float m_pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
 RT_DEV double m_pow5(double x) { return pow(x, 5.0); } // material.h:119 std::pow((1 - cosine),5)
+
+// sin / cos of 2*pi*x.  v_sin_f32 / v_cos_f32 take their argument in revolutions: one instruction each.
+RT_DEV void sincos_rev(float x, float &s, float &c) {
+    s = __builtin_amdgcn_sinf(x);
+    c = __builtin_amdgcn_cosf(x);
+}
+RT_DEV void sincos_rev(double x, double &s, double &c) {
+    const double phi = 2 * 3.1415926535897932385 * x; // 2*pi*r1 (vec3.h:146, sphere.h:104)
+    s = sin(phi);
+    c = cos(phi);
+}
+RT_DEV float sin_wide(float x) { // sin of an unreduced argument (noise texture): reduce in revolutions, then v_sin_f32
+    float r = x * 0.15915494309189535f;
+    return __builtin_amdgcn_sinf(r - floorf(r));
+}
+RT_DEV double sin_wide(double x) { return sin(x); }
 
 template <class R> struct Const;
 template <> struct Const<float> {
@@ -95,8 +111,11 @@ template <class R> RT_DEV V3<R> ray_at(const RayT<R> &r, R t) { return r.o + sca
 // oracle/rt_oracle.cpp's so that f64 renders can be compared path by path.
 RT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t &o0,
                           uint32_t &o1, uint32_t &o2, uint32_t &o3) {
+#ifndef RT_PHILOX_ROUNDS
+#define RT_PHILOX_ROUNDS 10
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < RT_PHILOX_ROUNDS; r++) {
         uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
         uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
         uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
@@ -111,29 +130,38 @@ template <class R> RT_DEV R u01(uint32_t x);
 template <> RT_DEV double u01<double>(uint32_t x) { return x * (1.0 / 4294967296.0); }
 template <> RT_DEV float u01<float>(uint32_t x) { return (x >> 8) * (1.0f / 16777216.0f); }
 
+// Stream protocol (shared with oracle/rt_oracle.cpp): counter = (block, sample, pixel, stream); stream 0 = the camera
+// ray's draws (get_ray), 0x80000000|b = the draws of ray_color invocation b of the path (scatter + mixture pdf),
+// 1+b = constant_medium draws keyed by node id.  begin*() computes block 0 unconditionally -- a wave-uniform point, so
+// the common case (<= 4 draws per bounce) never runs the generator under a divergent branch; no state survives a bounce.
 template <class R> struct Rng {
-    uint32_t k0, k1, pixel, sample, block;
+    uint32_t k0, k1, pixel, sample, stream, block;
     uint32_t b0, b1, b2, b3;
     int have;
-    RT_DEV void begin(uint32_t px, uint32_t s) { pixel = px; sample = s; block = 0; have = 0; }
+    RT_DEV void refill() {
+        philox4x32_10(block, sample, pixel, stream, k0, k1, b0, b1, b2, b3);
+        block++;
+        have = 4;
+    }
+    RT_DEV void begin(uint32_t px, uint32_t s) { pixel = px; sample = s; stream = 0u; block = 0; refill(); }
+    RT_DEV void begin_bounce(uint32_t px, uint32_t s, int bounce) {
+        pixel = px; sample = s; stream = 0x80000000u | (uint32_t)bounce; block = 0; refill();
+    }
     RT_DEV R next() { // utils.h:33 random_double()
-        if (have == 0) {
-            philox4x32_10(block, sample, pixel, 0u, k0, k1, b0, b1, b2, b3);
-            block++;
-            have = 4;
-        }
+        if (have == 0) refill();
         uint32_t x = b0;
         b0 = b1; b1 = b2; b2 = b3;
         have--;
         return u01<R>(x);
     }
     RT_DEV R next(R mn, R mx) { return mn + (mx - mn) * next(); } // utils.h:38
-    RT_DEV R medium(int node_id, int bounce) const {              // keyed draw for constant_medium.h:41
-        uint32_t o0, o1, o2, o3;
-        philox4x32_10((uint32_t)node_id, sample, pixel, 1u + (uint32_t)bounce, k0, k1, o0, o1, o2, o3);
-        return u01<R>(o0);
-    }
 };
+// keyed draw for constant_medium.h:41
+template <class R> RT_DEV R medium_draw(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, int node_id, int bounce) {
+    uint32_t o0, o1, o2, o3;
+    philox4x32_10((uint32_t)node_id, sample, pixel, 1u + (uint32_t)bounce, k0, k1, o0, o1, o2, o3);
+    return u01<R>(o0);
+}
 
 // ------------------------------------------------------------------------------------------------ scene memory
 // The leading sc.lds_units units of the record stream live in LDS (staged by stage_stream()), the rest in global
@@ -174,10 +202,28 @@ template <class R, bool ALL_LDS> struct Mem {
     }
 };
 
-template <class R> RT_DEV void stage_stream(const SceneT<R> &sc) {
+// Stage the stream prefix (and, when it fits, the shading tables) into LDS; returns the scene whose table pointers
+// address the LDS copies (generic pointers: flat loads resolve them).
+template <class R> RT_DEV SceneT<R> stage_scene(const SceneT<R> &sc) {
     UnitT<R> *l = reinterpret_cast<UnitT<R> *>(rt_smem);
     for (int k = threadIdx.x; k < sc.lds_units; k += blockDim.x) l[k] = sc.stream[k];
+    SceneT<R> o = sc;
+    if (sc.tab_in_lds) {
+        unsigned char *dst = rt_smem + (size_t)sc.lds_units * sizeof(UnitT<R>);
+        const rt_f4 *src = reinterpret_cast<const rt_f4 *>(sc.tab);
+        rt_f4 *d4 = reinterpret_cast<rt_f4 *>(dst);
+        for (int k = threadIdx.x; k < sc.tab_bytes / 16; k += blockDim.x) d4[k] = src[k];
+        const unsigned char *base = dst; // decays to a generic pointer
+        auto rebase = [&](const void *p) { return base + (reinterpret_cast<const uint8_t *>(p) - sc.tab); };
+        o.xforms = reinterpret_cast<const XformT<R> *>(rebase(sc.xforms));
+        o.mats = reinterpret_cast<const MatT<R> *>(rebase(sc.mats));
+        o.texs = reinterpret_cast<const TexT<R> *>(rebase(sc.texs));
+        o.images = reinterpret_cast<const ImageT *>(rebase(sc.images));
+        o.perlins = reinterpret_cast<const PerlinT<R> *>(rebase(sc.perlins));
+        o.lights = reinterpret_cast<const LightT<R> *>(rebase(sc.lights));
+    }
     __syncthreads();
+    return o;
 }
 
 // ------------------------------------------------------------------------------------------------ intersection
@@ -627,6 +673,7 @@ template <class R> RT_DEV V3<R> tex_value(const SceneT<R> &sc, int tex, R u, R v
         t = sc.texs[even ? t.a : t.b];
     }
     if (t.kind == RT_TEX_SOLID) return ld3(t.color); // texture.h:22
+#ifndef RT_EXP_NO_IMAGE
     if (t.kind == RT_TEX_IMAGE) {                    // texture.h:60
         if (t.a < 0) return mk<R>(R(0), R(1), R(1));
         const ImageT im = sc.images[t.a];
@@ -641,8 +688,15 @@ template <class R> RT_DEV V3<R> tex_value(const SceneT<R> &sc, int tex, R u, R v
         R cs = R(1.0) / R(255.0);
         return mk<R>(cs * px[0], cs * px[1], cs * px[2]);
     }
+#endif
+#ifdef RT_EXP_NO_NOISE
+    if (t.kind == RT_TEX_NOISE) return mk<R>(R(.5), R(.5), R(.5));
+#endif
+#ifdef RT_EXP_NO_IMAGE
+    if (t.kind == RT_TEX_IMAGE) return mk<R>(R(.5), R(.5), R(.5));
+#endif
     if (t.kind == RT_TEX_NOISE) { // texture.h:85
-        R s = R(1) + m_sin(t.scale * p.z + R(10) * perlin_turb(sc.perlins[t.a], p, 7));
+        R s = R(1) + sin_wide(t.scale * p.z + R(10) * perlin_turb(sc.perlins[t.a], p, 7));
         return mk<R>(R(.5) * s, R(.5) * s, R(.5) * s);
     }
     return mk<R>(R(0), R(0), R(0));
@@ -686,9 +740,10 @@ template <> RT_DEV V3<float> random_unit_vector<float>(Rng<float> &g) {
 template <class R> RT_DEV V3<R> random_cosine_direction(Rng<R> &g) { // vec3.h:142
     R r1 = g.next();
     R r2 = g.next();
-    R phi = R(2) * Const<R>::pi * r1;
     R sr = m_sqrt(r2);
-    return mk<R>(m_cos(phi) * sr, m_sin(phi) * sr, m_sqrt(R(1) - r2));
+    R sp, cp;
+    sincos_rev(r1, sp, cp); // phi = 2*pi*r1
+    return mk<R>(cp * sr, sp * sr, m_sqrt(R(1) - r2));
 }
 
 // `generated` = this light produced `dir` (light_random picked it), so in exact arithmetic the direction hits it.  In
@@ -760,14 +815,15 @@ template <class R> RT_DEV V3<R> light_random(const SceneT<R> &sc, V3<R> origin, 
         }
         R cm = m_sqrt(R(1) - x);
         R z = R(1) + r2 * (cm - R(1));
-        R phi = R(2) * Const<R>::pi * r1;
+        R sp, cp;
+        sincos_rev(r1, sp, cp); // phi = 2*pi*r1
         R s = m_sqrt(R(1) - z * z);
         if constexpr (sizeof(R) == 4) { // 1-z = r2*x/(1+cm) exactly; sqrt(1-z^2) = sqrt((1-z)(1+z)) keeps the small cone angle
             R omz = r2 * x / (R(1) + cm);
             z = R(1) - omz;
             s = m_sqrt(omz * (R(1) + z));
         }
-        return uvw.transform(mk<R>(m_cos(phi) * s, m_sin(phi) * s, z));
+        return uvw.transform(mk<R>(cp * s, sp * s, z));
     }
     if (L.kind == LIGHT_QUAD) { // quad.h:86
         R rv = g.next();
@@ -805,8 +861,10 @@ template <class R> RT_DEV RayT<R> get_ray(const CameraT<R> &cam, int i, int j, i
 template <class R, bool ALL_LDS>
 RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const CameraT<R> &cam, RayT<R> &ray, R best_t, int best_off,
                   int best_ctx, V3<R> &beta, V3<R> &L, Rng<R> &g) {
+    // L is written only when the path ends here: every hit that scatters emits nothing (material.h:28-31), so the
+    // recursion's sum of emissions has exactly one non-zero term, beta * (emitted | background).
     if (best_off < 0) { // camera.h:300
-        L = L + beta * ld3(cam.background);
+        L = beta * ld3(cam.background);
         return false;
     }
     Hit<R> h = finalize(mem, sc, ray, best_t, best_off, best_ctx, false);
@@ -814,10 +872,9 @@ RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const CameraT
     V3<R> emitted = mk<R>(R(0), R(0), R(0));
     if (m.kind == RT_MAT_DIFFUSE_LIGHT) { // material.h:129
         if (h.front) emitted = tex_value(sc, m.tex, h.u, h.v, h.p);
-        L = L + beta * emitted;
+        L = beta * emitted;
         return false; // material.h:28: no scatter
     }
-    L = L + beta * emitted; // keeps inf*0 -> NaN semantics of the recursive form
     if (m.kind == RT_MAT_METAL) { // material.h:66
         V3<R> reflected = reflect(ray.d, h.n);
         V3<R> ruv = random_unit_vector(g);
@@ -892,9 +949,9 @@ struct RenderArgs {
 // chosen wave-uniformly, so the hot BOX step is never serialised behind leaf or shading code that only a few lanes
 // need (64-lane divergence is the limiter of this workload: see DESIGN.md, profiles/).
 template <class R, bool ALL_LDS, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc, CameraT<R> cam, RenderArgs a, float *__restrict__ out,
+__global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT<R> cam, RenderArgs a, float *__restrict__ out,
                                                        unsigned long long *__restrict__ counters) {
-    stage_stream(sc);
+    const SceneT<R> sc = stage_scene(sc_arg);
     const Mem<R, ALL_LDS> mem{sc.stream, sc.lds_units};
     const int lane = threadIdx.x & 63;
     const int n_tiles = a.tiles_x * a.tiles_y;
@@ -902,10 +959,11 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc, CameraT<R> 
     const int n_units = sc.n_units;
     const R tmin = R(0.001);
     unsigned rays = 0;
-    Rng<R> g;
-    g.k0 = a.k0;
-    g.k1 = a.k1;
-    g.have = 0;
+    const uint32_t k0 = a.k0, k1 = a.k1;
+#ifdef RT_PROFILE_ACTIONS
+    unsigned long long prof_cyc[3] = {0, 0, 0}, prof_trips[3] = {0, 0, 0}, prof_lanes[3] = {0, 0, 0};
+    const unsigned long long t_wave0 = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
         int item = 0;
         if (lane == 0) item = (int)atomicAdd(&counters[1], 1ull);
@@ -924,7 +982,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc, CameraT<R> 
         // the float path sums an item in float and the items of a pixel in double, reduce_chunks_kernel)
         typename Accum<R>::type ax = 0, ay = 0, az = 0;
         RayT<R> ray;
-        V3<R> beta, L;
+        V3<R> beta;
         Trav<R> tv;
         tv.i = n_units;
         tv.hdr = 0;
@@ -935,10 +993,12 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc, CameraT<R> 
         auto next_path = [&]() {
             have_path = false;
             while (s < s_end) {
+                Rng<R> g;
+                g.k0 = k0;
+                g.k1 = k1;
                 g.begin(pixel, (uint32_t)s);
                 ray = get_ray(cam, i, j, s % cam.sqrt_spp, s / cam.sqrt_spp, g);
                 beta = mk<R>(R(1), R(1), R(1));
-                L = mk<R>(R(0), R(0), R(0));
                 depth = cam.max_depth;
                 if (depth > 0) { // camera.h:294
                     rays++;
@@ -966,20 +1026,29 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc, CameraT<R> 
             else if (mb) action = 0;
             else if (ml) action = 1;
             else action = 2;
+#ifdef RT_PROFILE_ACTIONS
+            const unsigned long long t_a = __builtin_amdgcn_s_memtime();
+            const int n_act = action == 0 ? __popcll(mb) : (action == 1 ? nl : nr);
+#endif
             if (action == 0) {
                 if (is_box) trav_box_step(mem, n_units, tv, tmin);
             } else if (action == 1) {
                 if (is_leaf) {
                     const int bounce_idx = cam.max_depth - depth;
-                    auto mxi = [&](int node_id) { return g.medium(node_id, bounce_idx); };
+                    auto mxi = [&](int node_id) { return medium_draw<R>(k0, k1, pixel, (uint32_t)s, node_id, bounce_idx); };
                     trav_leaf_step(mem, sc, tv, ray, tmin, mxi);
                 }
             } else {
                 if (ready) {
+                    Rng<R> g;
+                    g.k0 = k0;
+                    g.k1 = k1;
+                    g.begin_bounce(pixel, (uint32_t)s, cam.max_depth - depth);
+                    V3<R> L;
                     bool alive = shade(mem, sc, cam, ray, tv.best_t, tv.best_off, tv.best_ctx, beta, L, g);
                     depth--;
                     if (alive && depth == 0) { // depth exhausted: the recursion returns 0 here (camera.h:294-295)
-                        L = L + beta * mk<R>(R(0), R(0), R(0));
+                        L = beta * mk<R>(R(0), R(0), R(0));
                         alive = false;
                     }
                     if (alive) {
@@ -992,6 +1061,15 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc, CameraT<R> 
                     }
                 }
             }
+#ifdef RT_PROFILE_ACTIONS
+            { // diagnostic build only: cycles, trips and active lanes per action -> counters[4 + 3*action ...]
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_a;
+                prof_cyc[action] += dt;
+                prof_trips[action] += 1;
+                prof_lanes[action] += (unsigned long long)n_act;
+            }
+#endif
         }
         if (inside) {
             size_t o = ((size_t)chunk * cam.H * cam.W + (size_t)j * cam.W + i) * 3;
@@ -1001,6 +1079,16 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc, CameraT<R> 
     // wave-level ray count -> one atomic per wave
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_xor(rays, off);
     if (lane == 0) atomicAdd(&counters[0], (unsigned long long)rays);
+#ifdef RT_PROFILE_ACTIONS
+    if (lane == 0) {
+        for (int k = 0; k < 3; k++) {
+            atomicAdd(&counters[4 + 3 * k], prof_cyc[k]);
+            atomicAdd(&counters[5 + 3 * k], prof_trips[k]);
+            atomicAdd(&counters[6 + 3 * k], prof_lanes[k]);
+        }
+        atomicAdd(&counters[13], __builtin_amdgcn_s_memtime() - t_wave0);
+    }
+#endif
 }
 
 struct TraceArgs {
@@ -1010,9 +1098,9 @@ struct TraceArgs {
 
 // rt_trace_batch: closest hit of each ray over [0.001, inf) (camera.h:300).
 template <class R, bool ALL_LDS, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) trace_kernel(SceneT<R> sc, const rt_ray *__restrict__ rays, const double *__restrict__ xi,
+__global__ void __launch_bounds__(BLOCK) trace_kernel(SceneT<R> sc_arg, const rt_ray *__restrict__ rays, const double *__restrict__ xi,
                                                       size_t n, rt_hit *__restrict__ out, TraceArgs a) {
-    stage_stream(sc);
+    const SceneT<R> sc = stage_scene(sc_arg);
     const Mem<R, ALL_LDS> mem{sc.stream, sc.lds_units};
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
         RayT<R> r;

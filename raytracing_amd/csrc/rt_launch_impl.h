@@ -26,9 +26,8 @@ hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const Rende
     a.tiles_y = (cam.H + 7) / 8;
     a.leaf_threshold = rl.leaf_threshold < 1 ? 1 : rl.leaf_threshold;
     a.shade_threshold = rl.shade_threshold < 1 ? 1 : rl.shade_threshold;
-    if (sc.lds_units < 0 || sc.lds_units > sc.n_units || (size_t)sc.lds_units * sizeof(UnitT<R>) > (size_t)C::lds_bytes)
-        return hipErrorInvalidValue;
-    const size_t lds = (size_t)sc.lds_units * sizeof(UnitT<R>);
+    const size_t lds = (size_t)sc.lds_units * sizeof(UnitT<R>) + (sc.tab_in_lds ? (size_t)sc.tab_bytes : 0);
+    if (sc.lds_units < 0 || sc.lds_units > sc.n_units || lds > (size_t)C::lds_bytes || (sc.tab_bytes & 15)) return hipErrorInvalidValue;
     const long long items = (long long)a.tiles_x * a.tiles_y * rl.n_chunks;
     const int waves_per_block = C::block / 64;
     long long want = (items + waves_per_block - 1) / waves_per_block;
@@ -56,9 +55,8 @@ hipError_t launch_trace(const SceneT<R> &sc, const rt_ray *d_rays, const double 
     a.k0 = k0;
     a.k1 = k1;
     a.has_xi = d_xi != nullptr;
-    if (sc.lds_units < 0 || sc.lds_units > sc.n_units || (size_t)sc.lds_units * sizeof(UnitT<R>) > (size_t)C::lds_bytes)
-        return hipErrorInvalidValue;
-    const size_t lds = (size_t)sc.lds_units * sizeof(UnitT<R>);
+    const size_t lds = (size_t)sc.lds_units * sizeof(UnitT<R>) + (sc.tab_in_lds ? (size_t)sc.tab_bytes : 0);
+    if (sc.lds_units < 0 || sc.lds_units > sc.n_units || lds > (size_t)C::lds_bytes || (sc.tab_bytes & 15)) return hipErrorInvalidValue;
     size_t want = (n + C::block - 1) / C::block, cap = (size_t)n_cus * C::blocks_per_cu;
     dim3 grid((unsigned)(want < cap ? want : cap), 1, 1), block(C::block, 1, 1);
     hipError_t e;

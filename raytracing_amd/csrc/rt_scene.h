@@ -171,6 +171,11 @@ template <class R> struct SceneT { // device pointers; passed to kernels by valu
     const uint8_t *image_bytes;
     const PerlinT<R> *perlins;
     const LightT<R> *lights;
+    // the shading tables (xforms .. lights) are one contiguous device range [tab, tab + tab_bytes); when tab_in_lds is
+    // set the kernels stage it into LDS behind the stream and shade from there
+    const uint8_t *tab;
+    int32_t tab_bytes;
+    int32_t tab_in_lds;
     int32_t n_units;
     int32_t lds_units; // leading units of `stream` that the kernels stage into LDS
     int32_t n_lights;

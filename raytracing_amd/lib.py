@@ -13,7 +13,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")  # RT_AMD_LIB: diagnostic builds
 
 EXPORTS = ["rt_abi_sizeof", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_upload", "rt_scene_free",
            "rt_scene_info", "rt_trace_batch", "rt_render_device", "rt_tonemap_device", "rt_render"]
