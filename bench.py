@@ -31,7 +31,7 @@ PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (vector), packed
 def cpu_baseline(scene, cores):
     """The oracle (CPU restatement of the reference algorithm, same Philox streams) on a bounded sample of the workload."""
     from tests import oracle_lib as O
-    W, H, spp = 480, 270, 64
+    W, H, spp = 960, 540, 144  # ~75 M samples: 10-20 s on 16 host cores
     cam = camera.scene_camera(3, W, H, spp, 50)
     t0 = time.time()
     _, cnt = O.render(scene, cam, seed=1, rng_mode=1, threads=cores)
