@@ -28,9 +28,11 @@ struct rt_ctx {
     unsigned long long *counter = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cus = 256;
-    // development knobs (environment RT_AMD_LDS_UNITS / RT_AMD_LEAF_T / RT_AMD_SHADE_T); -1 / 0 = library default
+    // development knobs (environment RT_AMD_LDS_UNITS / RT_AMD_WEIGHTS / RT_AMD_SHADE_T); -1 / 0 = library default
     int lds_limit_units = -1;
-    int leaf_threshold = 0, shade_threshold = 0;
+    int shade_threshold = 0;
+    int weights[5] = {0, 0, 0, 0, 0};
+    int box_repeat = 0, box_repeat_min = 0;
 };
 
 template <class R> struct DeviceScene {
@@ -187,7 +189,7 @@ int rt_init(int device, rt_ctx **out) {
         delete ctx;
         return RT_ERR_HIP;
     }
-    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&ctx->counter, 16 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&ctx->counter, 40 * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx;
         return RT_ERR_HIP;
@@ -195,7 +197,9 @@ int rt_init(int device, rt_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cus = prop.multiProcessorCount;
     if (const char *e1 = std::getenv("RT_AMD_LDS_UNITS")) ctx->lds_limit_units = std::atoi(e1);
-    if (const char *e2 = std::getenv("RT_AMD_LEAF_T")) ctx->leaf_threshold = std::atoi(e2);
+    if (const char *e2 = std::getenv("RT_AMD_WEIGHTS")) // "box,sphere,aabox,medium,other"
+        std::sscanf(e2, "%d,%d,%d,%d,%d", &ctx->weights[0], &ctx->weights[1], &ctx->weights[2], &ctx->weights[3], &ctx->weights[4]);
+    if (const char *e4 = std::getenv("RT_AMD_BOX_REPEAT")) std::sscanf(e4, "%d,%d", &ctx->box_repeat, &ctx->box_repeat_min);
     if (const char *e3 = std::getenv("RT_AMD_SHADE_T")) ctx->shade_threshold = std::atoi(e3);
     *out = ctx;
     return RT_OK;
@@ -330,9 +334,12 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
     rl.chunk_size = chunk_size;
     rl.n_chunks = n_chunks;
     rl.n_cus = ctx->n_cus;
-    rl.leaf_threshold = ctx->leaf_threshold > 0 ? ctx->leaf_threshold : 16;
-    rl.shade_threshold = ctx->shade_threshold > 0 ? ctx->shade_threshold : 16;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->counter, 0, 16 * sizeof(unsigned long long), stream));
+    rl.shade_threshold = ctx->shade_threshold > 0 ? ctx->shade_threshold : 24;
+    rl.box_repeat = ctx->box_repeat > 0 ? ctx->box_repeat : 12;
+    rl.box_repeat_min = ctx->box_repeat_min > 0 ? ctx->box_repeat_min : 6;
+    static const int default_weights[5] = {2, 4, 4, 4, 4};
+    for (int k = 0; k < 5; k++) rl.weights[k] = ctx->weights[k] > 0 ? ctx->weights[k] : default_weights[k];
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counter, 0, 40 * sizeof(unsigned long long), stream));
     if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     if (params->precision == RT_PREC_F64)
         HIP_TRY(ctx, launch_render<double>(scene->f64.sc, convert_camera<double>(*cam), rl, target, ctx->counter, stream));
@@ -347,14 +354,21 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
         unsigned long long rays = 0;
         HIP_TRY(ctx, hipMemcpy(&rays, ctx->counter, sizeof(rays), hipMemcpyDeviceToHost));
         if (std::getenv("RT_AMD_PROFILE_ACTIONS")) { // diagnostic builds (-DRT_PROFILE_ACTIONS) fill counters[4..13]
-            unsigned long long c[16];
+            unsigned long long c[40];
             HIP_TRY(ctx, hipMemcpy(c, ctx->counter, sizeof(c), hipMemcpyDeviceToHost));
-            const char *nm[3] = {"box", "leaf", "shade"};
-            for (int k = 0; k < 3; k++)
-                std::fprintf(stderr, "[rt_amd profile] %-5s cycles %.4g (%.1f%% of wave time) trips %.4g cyc/trip %.1f lanes/trip %.1f\n",
-                             nm[k], (double)c[4 + 3 * k], 100.0 * (double)c[4 + 3 * k] / (double)(c[13] ? c[13] : 1), (double)c[5 + 3 * k],
+            const char *nm[6] = {"box", "sphere", "aabox", "medium", "other", "shade"};
+            for (int k = 0; k < 6; k++)
+                std::fprintf(stderr, "[rt_amd profile] %-6s cycles %.4g (%.1f%% of wave time) trips %.4g cyc/trip %.1f lanes/trip %.1f\n",
+                             nm[k], (double)c[4 + 3 * k], 100.0 * (double)c[4 + 3 * k] / (double)(c[3] ? c[3] : 1), (double)c[5 + 3 * k],
                              (double)c[4 + 3 * k] / (double)(c[5 + 3 * k] ? c[5 + 3 * k] : 1),
                              (double)c[6 + 3 * k] / (double)(c[5 + 3 * k] ? c[5 + 3 * k] : 1));
+        }
+        if (std::getenv("RT_AMD_PROFILE_ACTIONS")) {
+            unsigned long long c[40];
+            HIP_TRY(ctx, hipMemcpy(c, ctx->counter, sizeof(c), hipMemcpyDeviceToHost));
+            const char *nm[9] = {"rng begin", "finalize", "material+emit", "metal", "dielectric", "texture", "sample dir", "pdfs+weight", "tail (trav_begin / next_path)"};
+            for (int k = 0; k < 9; k++)
+                std::fprintf(stderr, "[rt_amd profile]   shade/%-30s %.1f%% of wave time\n", nm[k], 100.0 * (double)c[24 + k] / (double)(c[3] ? c[3] : 1));
         }
         stats->samples = (uint64_t)n_px * (uint64_t)n_samples;
         stats->rays = rays;

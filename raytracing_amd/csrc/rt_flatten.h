@@ -371,7 +371,7 @@ template <class R> class Flattener {
             const bool moving = s.dcenter[0] != 0 || s.dcenter[1] != 0 || s.dcenter[2] != 0;
             const int off = push_units(moving ? 3 : 2, id);
             f_.stream[off] = UnitT<R>{{F(s.center[0]), F(s.center[1]), F(s.center[2]), F(s.radius)}};
-            f_.stream[off + 1] = UnitT<R>{{I(s.mat), I(0), I(0), I(make_hdr(K_SPHERE, moving ? 1 : 0))}};
+            f_.stream[off + 1] = UnitT<R>{{I(s.mat), I(0), I(0), I(make_hdr(moving ? K_MSPHERE : K_SPHERE, 0))}};
             if (moving) f_.stream[off + 2] = UnitT<R>{{F(s.dcenter[0]), F(s.dcenter[1]), F(s.dcenter[2]), R(0)}};
             return RT_OK;
         }

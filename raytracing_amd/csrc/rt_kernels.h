@@ -425,6 +425,8 @@ template <class R, bool ALL_LDS> RT_DEV void trav_goto(const Mem<R, ALL_LDS> &me
         tv.u0 = mem.ld(i);
         tv.u1 = mem.ld(i + 1);
         tv.hdr = ldi(tv.u1.w[3]);
+    } else {
+        tv.hdr = K_READY; // traversal finished
     }
 }
 
@@ -454,9 +456,9 @@ RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, Trav
     const int kind = tv.hdr & 15;
     const int i = tv.i;
     int next = i + 2;
-    if (kind == K_SPHERE) {
+    if (kind == K_SPHERE || kind == K_MSPHERE) {
         V3<R> cc = mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]);
-        if (tv.hdr >> 4) { // moving sphere: centre = c + time*d (sphere.h:30)
+        if (kind == K_MSPHERE) { // moving sphere: centre = c + time*d (sphere.h:30)
             const UnitT<R> u2 = mem.ld(i + 2);
             cc = cc + scale<R>(world.tm, mk<R>(u2.w[0], u2.w[1], u2.w[2]));
             next = i + 3;
@@ -539,9 +541,9 @@ RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const Ra
     h.kind = hdr & 15;
     const RayT<R> r = ray_in_ctx(sc, world, best_ctx);
     h.p = ray_at(r, best_t);
-    if (h.kind == K_SPHERE) {
+    if (h.kind == K_SPHERE || h.kind == K_MSPHERE) {
         V3<R> cc = mk<R>(u0.w[0], u0.w[1], u0.w[2]);
-        if (hdr >> 4) {
+        if (h.kind == K_MSPHERE) {
             const UnitT<R> u2 = mem.ld(best_off + 2);
             cc = cc + scale<R>(r.tm, mk<R>(u2.w[0], u2.w[1], u2.w[2]));
         } else if constexpr (sizeof(R) == 8) {
@@ -856,11 +858,28 @@ template <class R> RT_DEV RayT<R> get_ray(const CameraT<R> &cam, int i, int j, i
     return r;
 }
 
+#ifdef RT_PROFILE_ACTIONS
+struct ShadeProf { unsigned long long last, sec[8]; };
+#define RT_SP_PARAM , ShadeProf &sp
+#define RT_SP_ARG , sp
+#define RT_STAMP(k)                                                                                                   \
+    do {                                                                                                               \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                    \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                    \
+        sp.sec[k] += t_ - sp.last;                                                                                     \
+        sp.last = t_;                                                                                                  \
+    } while (0)
+#else
+#define RT_SP_PARAM
+#define RT_SP_ARG
+#define RT_STAMP(k)
+#endif
+
 // The part of camera::ray_color (camera.h:291-326) that follows world.hit(), written iteratively: radiance
 // L += beta * (emitted | background), beta *= attenuation * scattering_pdf / pdf.  Returns false when the path ends.
 template <class R, bool ALL_LDS>
 RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const CameraT<R> &cam, RayT<R> &ray, R best_t, int best_off,
-                  int best_ctx, V3<R> &beta, V3<R> &L, Rng<R> &g) {
+                  int best_ctx, V3<R> &beta, V3<R> &L, Rng<R> &g RT_SP_PARAM) {
     // L is written only when the path ends here: every hit that scatters emits nothing (material.h:28-31), so the
     // recursion's sum of emissions has exactly one non-zero term, beta * (emitted | background).
     if (best_off < 0) { // camera.h:300
@@ -868,6 +887,7 @@ RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const CameraT
         return false;
     }
     Hit<R> h = finalize(mem, sc, ray, best_t, best_off, best_ctx, false);
+    RT_STAMP(1);
     const MatT<R> m = sc.mats[h.mat];
     V3<R> emitted = mk<R>(R(0), R(0), R(0));
     if (m.kind == RT_MAT_DIFFUSE_LIGHT) { // material.h:129
@@ -875,6 +895,7 @@ RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const CameraT
         L = beta * emitted;
         return false; // material.h:28: no scatter
     }
+    RT_STAMP(2);
     if (m.kind == RT_MAT_METAL) { // material.h:66
         V3<R> reflected = reflect(ray.d, h.n);
         V3<R> ruv = random_unit_vector(g);
@@ -884,6 +905,7 @@ RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const CameraT
         ray.d = reflected;
         return true;
     }
+    RT_STAMP(3);
     if (m.kind == RT_MAT_DIELECTRIC) { // material.h:88
         R ri = h.front ? (R(1.0) / m.ior) : m.ior;
         V3<R> ud = unit(ray.d);
@@ -904,13 +926,16 @@ RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const CameraT
         return true;
     }
     // lambertian / isotropic: mixture of light sampling and BRDF sampling (camera.h:313-325, pdf.h:69-85)
+    RT_STAMP(4);
     const bool lambert = (m.kind == RT_MAT_LAMBERTIAN);
     V3<R> atten = tex_value(sc, m.tex, h.u, h.v, h.p);
+    RT_STAMP(5);
     V3<R> dir;
     int picked = -1;
     if (g.next() < R(0.5)) dir = light_random(sc, h.p, g, picked);
     else if (lambert) dir = Onb<R>(h.n).transform(random_cosine_direction(g)); // pdf.h:40
     else dir = random_unit_vector(g);                                          // pdf.h:25
+    RT_STAMP(6);
     R v0 = light_pdf(sc, h.p, dir, picked);
     R v1, spdf;
     if (lambert) {
@@ -927,6 +952,7 @@ RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const CameraT
     beta = beta * scale<R>(wgt, atten);
     ray.o = h.p;
     ray.d = dir;
+    RT_STAMP(7);
     return true;
 }
 
@@ -938,9 +964,11 @@ struct RenderArgs {
     int32_t chunk_size;
     int32_t tiles_x, tiles_y;
     int32_t n_chunks;
-    int32_t leaf_threshold;  // run the leaf code once this many lanes wait at a non-BOX record
-    int32_t shade_threshold; // run the shading code once this many lanes have finished their traversal
+    int32_t shade_threshold; // run the shading block once this many lanes have finished their traversal
+    int32_t w_box, w_sphere, w_aabox, w_medium, w_other; // weights of the waiting-lane counts when choosing a block
+    int32_t box_repeat, box_repeat_min;                  // up to box_repeat BOX steps per trip while >= box_repeat_min lanes stay at BOX
 };
+enum : int { A_BOX = 0, A_SPHERE = 1, A_AABOX = 2, A_MEDIUM = 3, A_OTHER = 4, A_SHADE = 5, A_COUNT = 6 };
 
 // Persistent megakernel.  A workgroup stages the scene stream into LDS once, then each of its waves pulls work items
 // (8x8 pixel tile x chunk of the stratified sample range) from a global cursor.  Inside an item every lane owns a pixel
@@ -961,8 +989,10 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     unsigned rays = 0;
     const uint32_t k0 = a.k0, k1 = a.k1;
 #ifdef RT_PROFILE_ACTIONS
-    unsigned long long prof_cyc[3] = {0, 0, 0}, prof_trips[3] = {0, 0, 0}, prof_lanes[3] = {0, 0, 0};
+    unsigned long long prof_cyc[A_COUNT] = {}, prof_trips[A_COUNT] = {}, prof_lanes[A_COUNT] = {};
     const unsigned long long t_wave0 = __builtin_amdgcn_s_memtime();
+    ShadeProf sp{};
+    unsigned long long sp_tail = 0;
 #endif
     for (;;) {
         int item = 0;
@@ -985,13 +1015,11 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
         V3<R> beta;
         Trav<R> tv;
         tv.i = n_units;
-        tv.hdr = 0;
+        tv.hdr = K_IDLE;
         int depth = 0;
-        bool have_path = false;
 
         // start the next camera path of this lane (or retire the lane)
         auto next_path = [&]() {
-            have_path = false;
             while (s < s_end) {
                 Rng<R> g;
                 g.k0 = k0;
@@ -1003,49 +1031,100 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                 if (depth > 0) { // camera.h:294
                     rays++;
                     trav_begin(mem, n_units, tv, ray);
-                    have_path = true;
                     return;
                 }
                 s++; // max_depth <= 0: the sample is black
             }
             tv.i = n_units;
+            tv.hdr = K_IDLE;
         };
         next_path();
 
         for (;;) {
-            const bool trav = have_path && tv.i < n_units;
-            const bool is_box = trav && (tv.hdr & 15) == K_BOX;
-            const bool is_leaf = trav && !is_box;
-            const bool ready = have_path && !trav;
-            const unsigned long long mb = __ballot(is_box), ml = __ballot(is_leaf), mr = __ballot(ready);
-            if (!(mb | ml | mr)) break;
-            const int nl = __popcll(ml), nr = __popcll(mr);
-            int action; // 0 box, 1 leaf, 2 shade
-            if (nr >= a.shade_threshold) action = 2;
-            else if (nl >= a.leaf_threshold) action = 1;
-            else if (mb) action = 0;
-            else if (ml) action = 1;
-            else action = 2;
+            // lane state = low bits of tv.hdr: the kind of the record at the cursor, K_READY (traversal finished, waiting to
+            // be shaded) or K_IDLE (no samples left in this item)
+            const int kind = tv.hdr & 15;
+            const bool is_box = kind == K_BOX, is_sph = kind == K_SPHERE, is_aab = kind == K_AABOX, is_med = kind == K_MEDIUM;
+            const bool is_oth = kind >= K_QUAD && kind < K_IDLE; // quad, triangle, moving sphere, instance boundary
+            const bool ready = kind == K_READY;
+            const unsigned long long mb = __ballot(is_box), ms = __ballot(is_sph), ma = __ballot(is_aab), mm = __ballot(is_med),
+                                     mo = __ballot(is_oth), mr = __ballot(ready);
+            if (!(mb | ms | ma | mm | mo | mr)) break;
+            // Run ONE block per trip: shading once enough lanes wait for it, else the record kind with the largest weighted
+            // number of waiting lanes (score = count * weight, block id in the low bits -> one max chain).
+            const int nr = __popcll(mr);
+            int action = A_SHADE;
+            if (nr < a.shade_threshold) {
+                const unsigned sb = ((unsigned)(__popcll(mb) * a.w_box) << 3) | A_BOX, ss = ((unsigned)(__popcll(ms) * a.w_sphere) << 3) | A_SPHERE,
+                               sa = ((unsigned)(__popcll(ma) * a.w_aabox) << 3) | A_AABOX, sm = ((unsigned)(__popcll(mm) * a.w_medium) << 3) | A_MEDIUM,
+                               so = ((unsigned)(__popcll(mo) * a.w_other) << 3) | A_OTHER;
+                unsigned best = sb > ss ? sb : ss;
+                best = best > sa ? best : sa;
+                best = best > sm ? best : sm;
+                best = best > so ? best : so;
+                if (best >= 8u) action = (int)(best & 7u);
+            }
 #ifdef RT_PROFILE_ACTIONS
             const unsigned long long t_a = __builtin_amdgcn_s_memtime();
-            const int n_act = action == 0 ? __popcll(mb) : (action == 1 ? nl : nr);
+            const int n_act = action == A_BOX ? __popcll(mb) : action == A_SPHERE ? __popcll(ms) : action == A_AABOX ? __popcll(ma)
+                              : action == A_MEDIUM ? __popcll(mm) : action == A_OTHER ? __popcll(mo) : nr;
 #endif
-            if (action == 0) {
-                if (is_box) trav_box_step(mem, n_units, tv, tmin);
-            } else if (action == 1) {
-                if (is_leaf) {
+            if (action == A_BOX) {
+                // a few BOX steps in a row while enough lanes stay at BOX records (amortises the block selection)
+                bool at_box = is_box;
+                for (int rep = 0; rep < a.box_repeat; rep++) {
+                    if (at_box) {
+                        trav_box_step(mem, n_units, tv, tmin);
+                        at_box = (tv.hdr & 15) == K_BOX;
+                    }
+                    if (__popcll(__ballot(at_box)) < a.box_repeat_min) break;
+                }
+            } else if (action == A_SPHERE) {
+                if (is_sph) {
+                    V3<R> cc = mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]);
+                    if constexpr (sizeof(R) == 8) cc = cc + scale<R>(ray.tm, mk<R>(R(0), R(0), R(0))); // center.at(time), sphere.h:30
+                    R t;
+                    if (sphere_t(cc, tv.u0.w[3], tv.o, tv.d, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx; }
+                    trav_goto(mem, n_units, tv, tv.i + 2);
+                }
+            } else if (action == A_AABOX) {
+                if (is_aab) {
+                    R t;
+                    if (aabox_t(tv.u0, tv.u1, tv.o, tv.inv, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx; }
+                    trav_goto(mem, n_units, tv, tv.i + 2);
+                }
+            } else if (action == A_MEDIUM) {
+                if (is_med) {
+                    const int bounce_idx = cam.max_depth - depth;
+                    auto mxi = [&](int node_id) { return medium_draw<R>(k0, k1, pixel, (uint32_t)s, node_id, bounce_idx); };
+                    R t;
+                    if (medium_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], tv.u1.w[0], ldi(tv.u1.w[2]), tv.o, tv.d, tmin,
+                                 tv.best_t, mxi, t)) {
+                        tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx;
+                    }
+                    trav_goto(mem, n_units, tv, tv.i + 2);
+                }
+            } else if (action == A_OTHER) {
+                if (is_oth) {
                     const int bounce_idx = cam.max_depth - depth;
                     auto mxi = [&](int node_id) { return medium_draw<R>(k0, k1, pixel, (uint32_t)s, node_id, bounce_idx); };
                     trav_leaf_step(mem, sc, tv, ray, tmin, mxi);
                 }
             } else {
                 if (ready) {
+#ifdef RT_PROFILE_ACTIONS
+                    sp.last = __builtin_amdgcn_s_memtime();
+#endif
                     Rng<R> g;
                     g.k0 = k0;
                     g.k1 = k1;
                     g.begin_bounce(pixel, (uint32_t)s, cam.max_depth - depth);
+                    RT_STAMP(0);
                     V3<R> L;
-                    bool alive = shade(mem, sc, cam, ray, tv.best_t, tv.best_off, tv.best_ctx, beta, L, g);
+                    bool alive = shade(mem, sc, cam, ray, tv.best_t, tv.best_off, tv.best_ctx, beta, L, g RT_SP_ARG);
+#ifdef RT_PROFILE_ACTIONS
+                    sp.last = __builtin_amdgcn_s_memtime();
+#endif
                     depth--;
                     if (alive && depth == 0) { // depth exhausted: the recursion returns 0 here (camera.h:294-295)
                         L = beta * mk<R>(R(0), R(0), R(0));
@@ -1059,15 +1138,21 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         s++;
                         next_path();
                     }
+#ifdef RT_PROFILE_ACTIONS
+                    {
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        sp_tail += __builtin_amdgcn_s_memtime() - sp.last;
+                    }
+#endif
                 }
             }
 #ifdef RT_PROFILE_ACTIONS
             { // diagnostic build only: cycles, trips and active lanes per action -> counters[4 + 3*action ...]
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_a;
-                prof_cyc[action] += dt;
-                prof_trips[action] += 1;
-                prof_lanes[action] += (unsigned long long)n_act;
+#pragma unroll
+                for (int k = 0; k < A_COUNT; k++)
+                    if (action == k) { prof_cyc[k] += dt; prof_trips[k] += 1; prof_lanes[k] += (unsigned long long)n_act; }
             }
 #endif
         }
@@ -1081,12 +1166,14 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     if (lane == 0) atomicAdd(&counters[0], (unsigned long long)rays);
 #ifdef RT_PROFILE_ACTIONS
     if (lane == 0) {
-        for (int k = 0; k < 3; k++) {
+        for (int k = 0; k < A_COUNT; k++) {
             atomicAdd(&counters[4 + 3 * k], prof_cyc[k]);
             atomicAdd(&counters[5 + 3 * k], prof_trips[k]);
             atomicAdd(&counters[6 + 3 * k], prof_lanes[k]);
         }
-        atomicAdd(&counters[13], __builtin_amdgcn_s_memtime() - t_wave0);
+        atomicAdd(&counters[3], __builtin_amdgcn_s_memtime() - t_wave0);
+        for (int k = 0; k < 8; k++) atomicAdd(&counters[24 + k], sp.sec[k]);
+        atomicAdd(&counters[32], sp_tail);
     }
 #endif
 }

@@ -24,8 +24,14 @@ hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const Rende
     a.n_chunks = rl.n_chunks;
     a.tiles_x = (cam.W + 7) / 8;
     a.tiles_y = (cam.H + 7) / 8;
-    a.leaf_threshold = rl.leaf_threshold < 1 ? 1 : rl.leaf_threshold;
     a.shade_threshold = rl.shade_threshold < 1 ? 1 : rl.shade_threshold;
+    a.w_box = rl.weights[0] < 1 ? 1 : rl.weights[0];
+    a.w_sphere = rl.weights[1] < 1 ? 1 : rl.weights[1];
+    a.w_aabox = rl.weights[2] < 1 ? 1 : rl.weights[2];
+    a.w_medium = rl.weights[3] < 1 ? 1 : rl.weights[3];
+    a.w_other = rl.weights[4] < 1 ? 1 : rl.weights[4];
+    a.box_repeat = rl.box_repeat < 1 ? 1 : rl.box_repeat;
+    a.box_repeat_min = rl.box_repeat_min < 1 ? 1 : rl.box_repeat_min;
     const size_t lds = (size_t)sc.lds_units * sizeof(UnitT<R>) + (sc.tab_in_lds ? (size_t)sc.tab_bytes : 0);
     if (sc.lds_units < 0 || sc.lds_units > sc.n_units || lds > (size_t)C::lds_bytes || (sc.tab_bytes & 15)) return hipErrorInvalidValue;
     const long long items = (long long)a.tiles_x * a.tiles_y * rl.n_chunks;

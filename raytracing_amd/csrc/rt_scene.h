@@ -14,7 +14,7 @@
 //
 //   record            units  unit0                     unit1                              unit2..
 //   BOX     (bvh_node)   2   bmin.xyz, bmax.x          bmax.y, bmax.z, skip, hdr
-//   SPHERE               2/3 c.xyz, radius             mat, -, -, hdr(payload bit0=moving)  d.xyz (moving: centre = c + time*d)
+//   SPHERE / MSPHERE     2/3 c.xyz, radius             mat, -, -, hdr                     d.xyz (MSPHERE: centre = c + time*d)
 //   AABOX   (box())      2   bmin.xyz, bmax.x          bmax.y, bmax.z, mat, hdr(payload = 6 face-orientation bits)
 //   QUAD                 5   n.xyz, D                  Q.xyz, hdr                         u.xyz, mat | v.xyz, area | w.xyz, -
 //   TRI                  3   v0.xyz, e1.x              e1.y, e1.z, e2.x, hdr              e2.y, e2.z, mat, cull
@@ -35,15 +35,20 @@
 
 namespace rtamd {
 
+// Record kinds.  0..3 are the kinds that have a code block of their own in the render kernel's wave machine, >= 4 share
+// the "other" block; 14 / 15 never occur in the stream: they mark a lane's cursor as idle / past the end of the stream.
 enum : int {
     K_BOX = 0,
-    K_SPHERE = 1,
-    K_QUAD = 2,
-    K_TRI = 3,
-    K_MEDIUM = 4,
-    K_XF_ENTER = 5,
-    K_XF_EXIT = 6,
-    K_AABOX = 7,
+    K_SPHERE = 1, // static sphere
+    K_AABOX = 2,
+    K_MEDIUM = 3,
+    K_QUAD = 4,
+    K_TRI = 5,
+    K_XF_ENTER = 6,
+    K_XF_EXIT = 7,
+    K_MSPHERE = 8, // moving sphere (3 units)
+    K_IDLE = 14,
+    K_READY = 15,
 };
 enum : int { XF_TRANSLATE = 0, XF_ROTATE_Y = 1 };
 enum : int { MAX_XF_DEPTH = 4 };

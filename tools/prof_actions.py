@@ -5,6 +5,7 @@ from raytracing_amd import abi, lib, scenes
 name = sys.argv[1] if len(sys.argv) > 1 else "final_scene"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 W, H = (1920, 1080) if name != "cornell_box" else (600, 600)
+if len(sys.argv) > 4: W, H = int(sys.argv[3]), int(sys.argv[4])
 scene = scenes.build(name, W, H, spp, 50)
 ctx = lib.Context(0); ds = ctx.upload(scene)
 for rep in range(2):
