@@ -33,6 +33,7 @@ struct rt_ctx {
     int shade_threshold = 0;
     int weights[5] = {0, 0, 0, 0, 0};
     int box_repeat = 0, box_repeat_min = 0;
+    int min_chunk = 0, chunk_divisor = 0, max_chunk = 0;
 };
 
 template <class R> struct DeviceScene {
@@ -200,6 +201,7 @@ int rt_init(int device, rt_ctx **out) {
     if (const char *e2 = std::getenv("RT_AMD_WEIGHTS")) // "box,sphere,aabox,medium,other"
         std::sscanf(e2, "%d,%d,%d,%d,%d", &ctx->weights[0], &ctx->weights[1], &ctx->weights[2], &ctx->weights[3], &ctx->weights[4]);
     if (const char *e4 = std::getenv("RT_AMD_BOX_REPEAT")) std::sscanf(e4, "%d,%d", &ctx->box_repeat, &ctx->box_repeat_min);
+    if (const char *e5 = std::getenv("RT_AMD_CHUNKS")) std::sscanf(e5, "%d,%d,%d", &ctx->min_chunk, &ctx->chunk_divisor, &ctx->max_chunk);
     if (const char *e3 = std::getenv("RT_AMD_SHADE_T")) ctx->shade_threshold = std::atoi(e3);
     *out = ctx;
     return RT_OK;
@@ -303,35 +305,52 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
         if (stats) *stats = rt_stats{0, 0, 0.0};
         return RT_OK;
     }
-    // Work decomposition: a work item = (8x8 pixel tile, chunk of the sample range); waves pull items from a cursor.
-    // Enough chunks that every wave slot of the chip gets ~32 items (tail balance), but no chunk shorter than 24 samples
-    // (lanes regenerate paths inside a chunk; a short chunk wastes lanes while the last paths of an item finish).
+    // Work decomposition: a work item = (8x8 pixel tile, chunk of the sample range); waves pull items from a cursor in
+    // chunk-major order.  Default: a DECREASING-size schedule (each chunk takes a half / a third of what is left, down to a minimum),
+    // so the bulk of the samples runs in long items (lanes regenerate paths inside an item; a short item wastes lanes while
+    // its last paths finish) and the kernel ends on short ones (the end-of-kernel imbalance is one short item per wave).
+    // params->sample_chunks > 0 forces that many equal chunks instead.
     const int tiles = ((cam->image_width + 7) / 8) * ((cam->image_height + 7) / 8);
+    RenderLaunch rl{};
     int n_chunks = params->sample_chunks;
-    if (n_chunks <= 0) {
-        const int want_items = ctx->n_cus * 16 * 32;
-        n_chunks = (want_items + tiles - 1) / tiles;
+    const int wave_slots = ctx->n_cus * 16;
+    if (n_chunks <= 0 && tiles < 2 * wave_slots) { // small image: equal chunks, enough of them to give every wave ~32 items
+        n_chunks = (wave_slots * 32 + tiles - 1) / tiles;
         int max_chunks = n_samples / 24;
         if (max_chunks < 1) max_chunks = 1;
         if (n_chunks > max_chunks) n_chunks = max_chunks;
     }
-    if (n_chunks > n_samples) n_chunks = n_samples;
-    if (n_chunks < 1) n_chunks = 1;
-    if (n_chunks > 65535) n_chunks = 65535;
-    const int chunk_size = (n_samples + n_chunks - 1) / n_chunks;
-    n_chunks = (n_samples + chunk_size - 1) / chunk_size;
+    if (n_chunks > 0) {
+        if (n_chunks > n_samples) n_chunks = n_samples;
+        if (n_chunks > 65535) n_chunks = 65535;
+        rl.chunk_size = (n_samples + n_chunks - 1) / n_chunks;
+        n_chunks = (n_samples + rl.chunk_size - 1) / rl.chunk_size;
+    } else {
+        const int min_chunk = ctx->min_chunk > 0 ? ctx->min_chunk : 16;
+        const int divisor = ctx->chunk_divisor > 1 ? ctx->chunk_divisor : (n_samples >= 360 ? 3 : 2); // measured on final_scene 1080p
+        rl.chunk_size = 0;
+        n_chunks = 0;
+        int at = s_begin;
+        rl.chunk_start[0] = at;
+        while (at < s_end) {
+            int left = s_end - at, take = left / divisor;
+            if (ctx->max_chunk > 0 && take > ctx->max_chunk) take = ctx->max_chunk;
+            if (take < min_chunk) take = min_chunk;
+            if (take > left || left - take < min_chunk / 2 || n_chunks == 23) take = left;
+            at += take;
+            rl.chunk_start[++n_chunks] = at;
+        }
+    }
     float *target = d_accum;
     if (n_chunks > 1) {
         int rc = ensure(ctx, (void **)&ctx->partial, &ctx->partial_bytes, (size_t)n_chunks * n_px * 3 * sizeof(float));
         if (rc) return rc;
         target = ctx->partial;
     }
-    RenderLaunch rl;
     rl.k0 = (uint32_t)params->seed;
     rl.k1 = (uint32_t)(params->seed >> 32);
     rl.s_begin = s_begin;
     rl.s_end = s_end;
-    rl.chunk_size = chunk_size;
     rl.n_chunks = n_chunks;
     rl.n_cus = ctx->n_cus;
     rl.shade_threshold = ctx->shade_threshold > 0 ? ctx->shade_threshold : 24;

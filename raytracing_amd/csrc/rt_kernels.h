@@ -958,15 +958,17 @@ RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const CameraT
 
 template <class R> struct Accum { typedef R type; };
 
+enum : int { RT_MAX_SCHED_CHUNKS = 24 };
 struct RenderArgs {
     uint32_t k0, k1;
     int32_t s_begin, s_end;
-    int32_t chunk_size;
+    int32_t chunk_size;      // > 0: equal chunks of this many samples; 0: the boundaries in chunk_start[]
     int32_t tiles_x, tiles_y;
     int32_t n_chunks;
     int32_t shade_threshold; // run the shading block once this many lanes have finished their traversal
     int32_t w_box, w_sphere, w_aabox, w_medium, w_other; // weights of the waiting-lane counts when choosing a block
     int32_t box_repeat, box_repeat_min;                  // up to box_repeat BOX steps per trip while >= box_repeat_min lanes stay at BOX
+    int32_t chunk_start[RT_MAX_SCHED_CHUNKS + 1];        // decreasing-size schedule (chunk c = [chunk_start[c], chunk_start[c+1]))
 };
 enum : int { A_BOX = 0, A_SPHERE = 1, A_AABOX = 2, A_MEDIUM = 3, A_OTHER = 4, A_SHADE = 5, A_COUNT = 6 };
 
@@ -1003,9 +1005,15 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
         const int tj = tile / a.tiles_x, ti = tile - tj * a.tiles_x;
         const int i = ti * 8 + (lane & 7), j = tj * 8 + (lane >> 3);
         const bool inside = (i < cam.W) && (j < cam.H);
-        int s = a.s_begin + chunk * a.chunk_size;
-        int s_end = s + a.chunk_size;
-        if (s_end > a.s_end) s_end = a.s_end;
+        int s, s_end;
+        if (a.chunk_size > 0) {
+            s = a.s_begin + chunk * a.chunk_size;
+            s_end = s + a.chunk_size;
+            if (s_end > a.s_end) s_end = a.s_end;
+        } else {
+            s = a.chunk_start[chunk];
+            s_end = a.chunk_start[chunk + 1];
+        }
         if (!inside) s = s_end;
         const uint32_t pixel = (uint32_t)(j * cam.W + i);
         // per-pixel sum over the samples of this item (<= a few hundred; the reference sums in double: camera.h:175-181;

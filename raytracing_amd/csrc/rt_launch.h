@@ -11,6 +11,7 @@ namespace rtamd {
 struct RenderLaunch {
     uint32_t k0, k1;
     int32_t s_begin, s_end, chunk_size, n_chunks;
+    int32_t chunk_start[25]; // used when chunk_size == 0 (n_chunks <= 24)
     int32_t n_cus;
     int32_t shade_threshold;
     int32_t weights[5]; // box, sphere, aabox, medium, other

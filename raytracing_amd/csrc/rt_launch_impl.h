@@ -22,6 +22,8 @@ hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const Rende
     a.s_end = rl.s_end;
     a.chunk_size = rl.chunk_size;
     a.n_chunks = rl.n_chunks;
+    for (int k = 0; k <= RT_MAX_SCHED_CHUNKS; k++) a.chunk_start[k] = rl.chunk_start[k];
+    if (rl.chunk_size == 0 && (rl.n_chunks < 1 || rl.n_chunks > RT_MAX_SCHED_CHUNKS)) return hipErrorInvalidValue;
     a.tiles_x = (cam.W + 7) / 8;
     a.tiles_y = (cam.H + 7) / 8;
     a.shade_threshold = rl.shade_threshold < 1 ? 1 : rl.shade_threshold;
