@@ -16,7 +16,7 @@ python3 - $OUT <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
-for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True) + glob.glob(out + "/*/*counter_collection.csv"):
+for f in sorted(set(glob.glob(out + "/*/**/*counter_collection.csv", recursive=True))):
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"].split("(")[0][-60:]][r["Counter_Name"]] += float(r["Counter_Value"])
 for k, d in agg.items():
