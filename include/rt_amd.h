@@ -227,6 +227,12 @@ void rt_scene_free(rt_scene *scene);
 /* out[4] = { threaded device nodes, lights, f32 device bytes, f64 device bytes }. */
 int rt_scene_info(const rt_scene *scene, int32_t *out);
 
+/* Host-only (no GPU, no context): run the flattener on `desc` and report what rt_scene_upload would put on the device:
+ * out[0] = record-stream units of the f32 (production) stream, out[1] = units of the f64 (parity) stream,
+ * out[2] = box() lists fused into one AABOX record in the f32 stream (quad.h:103), out[3] = lights.
+ * Returns RT_OK or the status rt_scene_upload would return for this description.  No reference counterpart. */
+int rt_scene_flatten_info(const rt_scene_desc *desc, int32_t *out);
+
 /* Closest hit of each ray in [0.001, inf): replaces world.hit(r, interval(0.001, infinity), rec)
  * (camera.h:300 -> hittable_list.h:24 / bvh.h:43).  `xi` (optional, one per ray) is the uniform every
  * constant_medium on that ray consumes (constant_medium.h:41); NULL = counter-based RNG keyed by ray index.

@@ -256,6 +256,22 @@ int rt_scene_info(const rt_scene *scene, int32_t *out /* [4]: flat nodes, lights
     return RT_OK;
 }
 
+int rt_scene_flatten_info(const rt_scene_desc *desc, int32_t *out) {
+    if (!desc || !out) return RT_ERR_INVALID;
+    std::string err;
+    Flat<float> f32;
+    int rc = Flattener<float>(*desc, f32, err, true).run();
+    if (rc) return rc;
+    Flat<double> f64;
+    rc = Flattener<double>(*desc, f64, err, false).run();
+    if (rc) return rc;
+    out[0] = (int32_t)f32.stream.size();
+    out[1] = (int32_t)f64.stream.size();
+    out[2] = f32.n_fused_boxes;
+    out[3] = (int32_t)f32.lights.size();
+    return RT_OK;
+}
+
 int rt_trace_batch(rt_ctx *ctx, const rt_scene *scene, const rt_ray *rays, const double *xi, size_t n, rt_hit *out,
                    int precision) {
     if (!ctx || !scene || (n && (!rays || !out))) return set_err(ctx, RT_ERR_INVALID, "rt_trace_batch: null argument");

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")  # RT_AMD_LIB: diagnostic builds
 
 EXPORTS = ["rt_abi_sizeof", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_upload", "rt_scene_free",
-           "rt_scene_info", "rt_trace_batch", "rt_render_device", "rt_tonemap_device", "rt_render"]
+           "rt_scene_info", "rt_scene_flatten_info", "rt_trace_batch", "rt_render_device", "rt_tonemap_device", "rt_render"]
 
 _lib = None
 
@@ -48,6 +48,8 @@ def load() -> C.CDLL:
     L.rt_scene_free.argtypes = [vp]
     L.rt_scene_info.restype = C.c_int
     L.rt_scene_info.argtypes = [vp, vp]
+    L.rt_scene_flatten_info.restype = C.c_int
+    L.rt_scene_flatten_info.argtypes = [C.POINTER(abi.SceneDesc), vp]
     L.rt_trace_batch.restype = C.c_int
     L.rt_trace_batch.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, C.c_int]
     L.rt_render_device.restype = C.c_int
@@ -58,6 +60,17 @@ def load() -> C.CDLL:
     L.rt_render.argtypes = [vp, vp, vp, C.POINTER(abi.RenderParams), vp, vp, C.POINTER(abi.Stats)]
     _lib = L
     return L
+
+
+def flatten_info(scene: abi.Scene) -> dict:
+    """Host-only: what rt_scene_upload would build for `scene` (raises RtError with the status it would return)."""
+    L = load()
+    d = scene.desc()
+    out = np.zeros(4, dtype=np.int32)
+    rc = L.rt_scene_flatten_info(C.byref(d), out.ctypes.data)
+    if rc != abi.RT_OK:
+        raise RtError(f"rt_scene_flatten_info failed with status {rc}")
+    return {"f32_units": int(out[0]), "f64_units": int(out[1]), "fused_boxes": int(out[2]), "lights": int(out[3])}
 
 
 class Context:

@@ -92,3 +92,31 @@ def test_split_range_properties():
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
     assert sorted(sum((distributed.frame_shards(124, 8, r) for r in range(8)), [])) == list(range(124))
+
+
+def test_flattener_stream_sizes_and_box_fusion():
+    """Host-only run of the flattener (rt_scene_flatten_info): the f32 stream fuses every box() list of six axis-aligned
+    quads (quad.h:103) into one AABOX record, the f64 parity stream keeps the reference's quads; malformed graphs are
+    refused with a status instead of a crash."""
+    info = {n: lib.flatten_info(fx.scene(n)) for n in (1, 2, 3, 4)}
+    assert info[3]["fused_boxes"] == 400  # final_scene's ground: 400 boxes = 2400 quads (cpuRenderer.cpp:298-312)
+    assert info[1]["fused_boxes"] == 0 and info[4]["fused_boxes"] == 0
+    assert info[2]["fused_boxes"] == 1  # cornell's rotated box is axis-aligned in its own (object) space
+    for n in (1, 2, 3, 4):
+        assert info[n]["f32_units"] <= info[n]["f64_units"]
+    assert info[3]["f64_units"] - info[3]["f32_units"] == 400 * (6 * 5 - 2)  # six 5-unit quads -> one 2-unit record
+    assert info[1]["f32_units"] == info[1]["f64_units"]
+    assert [info[n]["lights"] for n in (1, 2, 3, 4)] == [1, 2, 1, 2]
+    # a box with one face moved is not fused
+    sc = fx.scene(2)
+    nodes = sc.nodes
+    lists = np.nonzero((nodes["kind"] == abi.RT_NODE_LIST) & (nodes["b"] == 6))[0]
+    assert len(lists) == 1
+    q = nodes["a"][sc.arrays["child_index"][nodes["a"][lists[0]]]]
+    sc.arrays["quads"]["Q"][q][0] += 1.0
+    sc.quads["Q"][q, 0] += 1.0
+    assert lib.flatten_info(sc)["fused_boxes"] == 0
+    bad = fx.scene(2)
+    bad.world_root = 10 ** 6
+    with pytest.raises(lib.RtError):
+        lib.flatten_info(bad)
