@@ -28,11 +28,8 @@ struct rt_ctx {
     unsigned long long *counter = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cus = 256;
-    // development knobs (environment RT_AMD_LDS_UNITS / RT_AMD_WEIGHTS / RT_AMD_SHADE_T); -1 / 0 = library default
+    // development knobs (environment RT_AMD_LDS_UNITS / RT_AMD_CHUNKS); -1 / 0 = library default
     int lds_limit_units = -1;
-    int shade_threshold = 0;
-    int weights[5] = {0, 0, 0, 0, 0};
-    int box_repeat = 0, box_repeat_min = 0;
     int min_chunk = 0, chunk_divisor = 0, max_chunk = 0;
 };
 
@@ -198,11 +195,7 @@ int rt_init(int device, rt_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cus = prop.multiProcessorCount;
     if (const char *e1 = std::getenv("RT_AMD_LDS_UNITS")) ctx->lds_limit_units = std::atoi(e1);
-    if (const char *e2 = std::getenv("RT_AMD_WEIGHTS")) // "box,sphere,aabox,medium,other"
-        std::sscanf(e2, "%d,%d,%d,%d,%d", &ctx->weights[0], &ctx->weights[1], &ctx->weights[2], &ctx->weights[3], &ctx->weights[4]);
-    if (const char *e4 = std::getenv("RT_AMD_BOX_REPEAT")) std::sscanf(e4, "%d,%d", &ctx->box_repeat, &ctx->box_repeat_min);
     if (const char *e5 = std::getenv("RT_AMD_CHUNKS")) std::sscanf(e5, "%d,%d,%d", &ctx->min_chunk, &ctx->chunk_divisor, &ctx->max_chunk);
-    if (const char *e3 = std::getenv("RT_AMD_SHADE_T")) ctx->shade_threshold = std::atoi(e3);
     *out = ctx;
     return RT_OK;
 }
@@ -369,11 +362,6 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
     rl.s_end = s_end;
     rl.n_chunks = n_chunks;
     rl.n_cus = ctx->n_cus;
-    rl.shade_threshold = ctx->shade_threshold > 0 ? ctx->shade_threshold : 24;
-    rl.box_repeat = ctx->box_repeat > 0 ? ctx->box_repeat : 12;
-    rl.box_repeat_min = ctx->box_repeat_min > 0 ? ctx->box_repeat_min : 6;
-    static const int default_weights[5] = {2, 4, 4, 4, 4};
-    for (int k = 0; k < 5; k++) rl.weights[k] = ctx->weights[k] > 0 ? ctx->weights[k] : default_weights[k];
     HIP_TRY(ctx, hipMemsetAsync(ctx->counter, 0, 40 * sizeof(unsigned long long), stream));
     if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     if (params->precision == RT_PREC_F64)

@@ -959,15 +959,30 @@ RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const CameraT
 template <class R> struct Accum { typedef R type; };
 
 enum : int { RT_MAX_SCHED_CHUNKS = 24 };
+// Scheduling constants of the render kernel's wave machine (tuned on final_scene 1080p, tools/sweep.py history in
+// DESIGN.md; compile-time so that they cost no SGPRs): weights of the waiting-lane counts when a block is chosen,
+// lanes that must wait before the shading block runs, BOX steps per trip while enough lanes stay at BOX records.
+#ifndef RT_W_BOX
+#define RT_W_BOX 2
+#endif
+#ifndef RT_W_LEAF
+#define RT_W_LEAF 4
+#endif
+#ifndef RT_SHADE_T
+#define RT_SHADE_T 24
+#endif
+#ifndef RT_BOX_REPEAT
+#define RT_BOX_REPEAT 12
+#endif
+#ifndef RT_BOX_REPEAT_MIN
+#define RT_BOX_REPEAT_MIN 6
+#endif
 struct RenderArgs {
     uint32_t k0, k1;
     int32_t s_begin, s_end;
     int32_t chunk_size;      // > 0: equal chunks of this many samples; 0: the boundaries in chunk_start[]
     int32_t tiles_x, tiles_y;
     int32_t n_chunks;
-    int32_t shade_threshold; // run the shading block once this many lanes have finished their traversal
-    int32_t w_box, w_sphere, w_aabox, w_medium, w_other; // weights of the waiting-lane counts when choosing a block
-    int32_t box_repeat, box_repeat_min;                  // up to box_repeat BOX steps per trip while >= box_repeat_min lanes stay at BOX
     int32_t chunk_start[RT_MAX_SCHED_CHUNKS + 1];        // decreasing-size schedule (chunk c = [chunk_start[c], chunk_start[c+1]))
 };
 enum : int { A_BOX = 0, A_SPHERE = 1, A_AABOX = 2, A_MEDIUM = 3, A_OTHER = 4, A_SHADE = 5, A_COUNT = 6 };
@@ -1062,10 +1077,10 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             // number of waiting lanes (score = count * weight, block id in the low bits -> one max chain).
             const int nr = __popcll(mr);
             int action = A_SHADE;
-            if (nr < a.shade_threshold) {
-                const unsigned sb = ((unsigned)(__popcll(mb) * a.w_box) << 3) | A_BOX, ss = ((unsigned)(__popcll(ms) * a.w_sphere) << 3) | A_SPHERE,
-                               sa = ((unsigned)(__popcll(ma) * a.w_aabox) << 3) | A_AABOX, sm = ((unsigned)(__popcll(mm) * a.w_medium) << 3) | A_MEDIUM,
-                               so = ((unsigned)(__popcll(mo) * a.w_other) << 3) | A_OTHER;
+            if (nr < RT_SHADE_T) {
+                const unsigned sb = ((unsigned)(__popcll(mb) * RT_W_BOX) << 3) | A_BOX, ss = ((unsigned)(__popcll(ms) * RT_W_LEAF) << 3) | A_SPHERE,
+                               sa = ((unsigned)(__popcll(ma) * RT_W_LEAF) << 3) | A_AABOX, sm = ((unsigned)(__popcll(mm) * RT_W_LEAF) << 3) | A_MEDIUM,
+                               so = ((unsigned)(__popcll(mo) * RT_W_LEAF) << 3) | A_OTHER;
                 unsigned best = sb > ss ? sb : ss;
                 best = best > sa ? best : sa;
                 best = best > sm ? best : sm;
@@ -1080,12 +1095,12 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             if (action == A_BOX) {
                 // a few BOX steps in a row while enough lanes stay at BOX records (amortises the block selection)
                 bool at_box = is_box;
-                for (int rep = 0; rep < a.box_repeat; rep++) {
+                for (int rep = 0; rep < RT_BOX_REPEAT; rep++) {
                     if (at_box) {
                         trav_box_step(mem, n_units, tv, tmin);
                         at_box = (tv.hdr & 15) == K_BOX;
                     }
-                    if (__popcll(__ballot(at_box)) < a.box_repeat_min) break;
+                    if (__popcll(__ballot(at_box)) < RT_BOX_REPEAT_MIN) break;
                 }
             } else if (action == A_SPHERE) {
                 if (is_sph) {

@@ -13,9 +13,6 @@ struct RenderLaunch {
     int32_t s_begin, s_end, chunk_size, n_chunks;
     int32_t chunk_start[25]; // used when chunk_size == 0 (n_chunks <= 24)
     int32_t n_cus;
-    int32_t shade_threshold;
-    int32_t weights[5]; // box, sphere, aabox, medium, other
-    int32_t box_repeat, box_repeat_min;
 };
 
 // LDS the kernels of precision R may use for the scene stream, and their workgroup size.

@@ -26,14 +26,6 @@ hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const Rende
     if (rl.chunk_size == 0 && (rl.n_chunks < 1 || rl.n_chunks > RT_MAX_SCHED_CHUNKS)) return hipErrorInvalidValue;
     a.tiles_x = (cam.W + 7) / 8;
     a.tiles_y = (cam.H + 7) / 8;
-    a.shade_threshold = rl.shade_threshold < 1 ? 1 : rl.shade_threshold;
-    a.w_box = rl.weights[0] < 1 ? 1 : rl.weights[0];
-    a.w_sphere = rl.weights[1] < 1 ? 1 : rl.weights[1];
-    a.w_aabox = rl.weights[2] < 1 ? 1 : rl.weights[2];
-    a.w_medium = rl.weights[3] < 1 ? 1 : rl.weights[3];
-    a.w_other = rl.weights[4] < 1 ? 1 : rl.weights[4];
-    a.box_repeat = rl.box_repeat < 1 ? 1 : rl.box_repeat;
-    a.box_repeat_min = rl.box_repeat_min < 1 ? 1 : rl.box_repeat_min;
     const size_t lds = (size_t)sc.lds_units * sizeof(UnitT<R>) + (sc.tab_in_lds ? (size_t)sc.tab_bytes : 0);
     if (sc.lds_units < 0 || sc.lds_units > sc.n_units || lds > (size_t)C::lds_bytes || (sc.tab_bytes & 15)) return hipErrorInvalidValue;
     const long long items = (long long)a.tiles_x * a.tiles_y * rl.n_chunks;
