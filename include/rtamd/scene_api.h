@@ -957,8 +957,6 @@ class camera {
     rt_stats last_stats{};
     bool write_file = true;
 
-    ~camera() { delete image; }
-
     // camera.h:157: one still frame to ./images/<filename>
     void render(const hittable &world, const hittable &lights) {
         initialize();
@@ -971,39 +969,48 @@ class camera {
     // its CPU build always runs the 42-frame translate sequence whatever was requested; method 0 below is the rotate +
     // zoom sequence that code was written to run (camera.h:48-97), method 1 the translate sequence (98-153).
     void render_animation(const hittable &world, const hittable &lights) {
-        if (animation_method == 0) {
-            vec3 direction = lookfrom - lookat;
-            double theta = std::acos(direction.y() / direction.length());
-            double phi = std::atan2(direction.x(), direction.z());
-            double zoom = 1.005;
-            for (int frame = 0; frame < animation_sample; frame++) {
-                rotate(theta, phi);
-                this->zoom(zoom);
-                initialize();
-                snprintf(filepath, sizeof(filepath), "./images/animation/image%d.ppm", frame);
-                render_frame(world, lights);
-                if (write_file) writePPMImage(image, filepath);
-                phi += delta_phi;
-                if (phi >= 2 * pi) phi -= 2 * pi;
-                theta -= 0.01;
-                if (theta <= 0) theta = 0;
-            }
-        } else {
-            double step = 0.6;
-            animation_sample = 42;
-            for (int frame = 0; frame < animation_sample; frame++) {
-                if (frame < 7) translate(FORWARD, step);
-                else if (frame < 14) translate(BACKWARD, step);
-                else if (frame < 21) translate(LEFT, step);
-                else if (frame < 28) translate(RIGHT, step);
-                else if (frame < 35) translate(UP, step);
-                else if (frame < 42) translate(DOWN, step);
-                initialize();
-                snprintf(filepath, sizeof(filepath), "./images/animation/image%d.ppm", frame);
-                render_frame(world, lights);
-                if (write_file) writePPMImage(image, filepath);
-            }
+        const int n = animation_frames();
+        for (int frame = 0; frame < n; frame++) {
+            animation_step(frame);
+            snprintf(filepath, sizeof(filepath), "./images/animation/image%d.ppm", frame);
+            render_frame(world, lights);
+            if (write_file) writePPMImage(image, filepath);
         }
+    }
+
+    // The camera path of render_animation() without the rendering, for drivers that shard frames over GPUs
+    // (frames are independent: frame f -> GPU f mod G): animation_frames() is the length of the sequence,
+    // animation_step(f), called for f = 0, 1, 2, ... in order, moves the camera to frame f and returns its frame.
+    int animation_frames() {
+        if (animation_method != 0) animation_sample = 42; // camera.h:100
+        return animation_sample;
+    }
+    rt_camera animation_step(int frame) {
+        if (animation_method == 0) { // camera.h:49-59, 93-96
+            if (frame == 0) {
+                vec3 direction = lookfrom - lookat;
+                anim_theta_ = std::acos(direction.y() / direction.length());
+                anim_phi_ = std::atan2(direction.x(), direction.z());
+            }
+            rotate(anim_theta_, anim_phi_);
+            zoom(1.005);
+            initialize();
+            anim_phi_ += delta_phi;
+            if (anim_phi_ >= 2 * pi) anim_phi_ -= 2 * pi;
+            anim_theta_ -= 0.01;
+            if (anim_theta_ <= 0) anim_theta_ = 0;
+        } else { // camera.h:99-119.  u, v, w are those of the previous initialize(): zero vectors on a fresh camera,
+                 // so the first FORWARD step only lengthens focus_dist, as in the reference
+            const double step = 0.6;
+            if (frame < 7) translate(FORWARD, step);
+            else if (frame < 14) translate(BACKWARD, step);
+            else if (frame < 21) translate(LEFT, step);
+            else if (frame < 28) translate(RIGHT, step);
+            else if (frame < 35) translate(UP, step);
+            else if (frame < 42) translate(DOWN, step);
+            initialize();
+        }
+        return frame_;
     }
 
     // The derived frame (camera.h:205-247) in the C-ABI form; public so that drivers can shard work themselves.
@@ -1015,8 +1022,8 @@ class camera {
         image_height = int(image_width / aspect_ratio);
         image_height = (image_height < 1) ? 1 : image_height;
         if (!image || image->width != image_width || image->height != image_height) {
-            delete image;
-            image = new Image(image_width, image_height);
+            image_owner_ = std::make_shared<Image>(image_width, image_height);
+            image = image_owner_.get();
         }
         image->clear(0, 0, 0);
         sqrt_spp = int(std::sqrt(samples_per_pixel));
@@ -1063,6 +1070,8 @@ class camera {
     point3 center, pixel00_loc;
     vec3 pixel_delta_u, pixel_delta_v, u, v, w, defocus_disk_u, defocus_disk_v;
     rt_camera frame_{};
+    double anim_theta_ = 0, anim_phi_ = 0;
+    std::shared_ptr<Image> image_owner_; // `image` points into it; copies of a camera share the buffer until re-initialised
 
     void render_frame(const hittable &world, const hittable &lights) {
         rtamd::FlatScene f;

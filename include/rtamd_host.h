@@ -24,6 +24,12 @@ rtamd_host_scene *rtamd_host_build_scene(int scene, int image_width, int image_h
 const rt_scene_desc *rtamd_host_scene_desc(const rtamd_host_scene *s);
 /* camera::initialize()'s frame for the scene's camera (camera.h:205-247) */
 int rtamd_host_scene_camera(const rtamd_host_scene *s, rt_camera *out);
+/* The camera frames of camera::render_animation (camera.h:46-154) for the scene's camera, without rendering: method 0
+ * = rotate + zoom (62 frames, camera.h:49-59,93-96), 1 = translate (42 frames, camera.h:99-119; what the reference's
+ * CPU build runs for every method, because camera.h:48,98 assign instead of compare).  Starts from the camera as the
+ * scene function leaves it (u,v,w still zero, like a fresh reference process).  Returns the number of frames (also
+ * with out == NULL), or a negative status if cap is too small.  Frames are independent: frame f -> GPU f mod G. */
+int rtamd_host_scene_animation(const rtamd_host_scene *s, int method, rt_camera *out, int cap);
 /* write the "RTSCENE1" container (scene + camera) */
 int rtamd_host_scene_save(const rtamd_host_scene *s, const char *path);
 void rtamd_host_scene_free(rtamd_host_scene *s);

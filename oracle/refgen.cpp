@@ -8,6 +8,10 @@
 // Modes (one per process):
 //   dump   : serialise the reference object graph + camera frame into the flat format of include/rt_amd.h
 //   trace  : deterministic ray batches through the reference's world.hit(); records hit_record + primitive id
+//   anim   : the reference's own first_scene(animation=true) -> camera::render_animation() (camera.h:46; its CPU build
+//            always runs the 42-frame translate sequence, see camera.h:48,98); every frame's camera and int image
+//   anim_rotate : the camera frames of the rotate + zoom sequence (camera.h:49-59, 93-96: dead code in the CPU build,
+//            so the harness drives the reference's rotate()/zoom()/initialize() in that order itself)
 //   render : the reference's pixel loop (get_ray / ray_color / write_color) single-threaded from srand(seed);
 //            records the double-precision pixel sums and the int bytes; cross-checked against the PPM written by
 //            the reference's real camera::render() in the same process.
@@ -54,8 +58,14 @@ extern "C" void srand(unsigned int seed) { srandom(seed); }
 
 #define private public
 #include "cpu/utils.h"
-#include "cpu/bvh.h"
+// every writePPMImage() call inside camera.h (render: 189, render_animation: 91, 151) goes through the harness, which
+// records the camera frame and the int image of each animation frame the reference's own loop produces
+class camera;
+static void on_write_ppm(camera *cam, const Image *image, const char *path);
+#define writePPMImage(img, path) on_write_ppm(this, (img), (path))
 #include "cpu/camera.h"
+#undef writePPMImage
+#include "cpu/bvh.h"
 #include "cpu/constant_medium.h"
 #include "cpu/hittable_list.h"
 #include "cpu/material.h"
@@ -318,8 +328,56 @@ static void set_unique_materials(Flat &f, std::map<const material *, int> &prim_
     }
 }
 
+struct AnimFrame {
+    rt_camera cam;
+    std::vector<int32_t> bytes;
+};
+static std::vector<AnimFrame> g_anim;
+
+static void on_write_ppm(camera *cam, const Image *image, const char *path) {
+    if (g_mode != "anim") {
+        writePPMImage(image, path);
+        return;
+    }
+    AnimFrame fr;
+    fr.cam = camera_frame(*cam);
+    fr.bytes.assign(image->data, image->data + (size_t)3 * image->width * image->height);
+    g_anim.push_back(std::move(fr));
+}
+
+static void write_anim(bool with_images) {
+    FILE *fp = fopen(g_out.c_str(), "wb");
+    if (!fp) { perror(g_out.c_str()); exit(2); }
+    fwrite("RTANIM01", 1, 8, fp);
+    int32_t hdr[4] = {(int32_t)g_anim.size(), g_anim.empty() ? 0 : g_anim[0].cam.image_width,
+                      g_anim.empty() ? 0 : g_anim[0].cam.image_height, with_images ? 1 : 0};
+    fwrite(hdr, sizeof(int32_t), 4, fp);
+    for (auto &fr : g_anim) fwrite(&fr.cam, sizeof(rt_camera), 1, fp);
+    if (with_images)
+        for (auto &fr : g_anim) fwrite(fr.bytes.data(), sizeof(int32_t), fr.bytes.size(), fp);
+    fclose(fp);
+    fprintf(stderr, "refgen: %zu animation frames\n", g_anim.size());
+}
+
 static void on_render(camera &cam, const hittable &world, const hittable &lights) {
     cam.use_openmp = false;
+    if (g_mode == "anim_rotate") { // camera.h:49-59, 93-96
+        vec3 direction = cam.lookfrom - cam.lookat;
+        double theta = std::acos(direction.y() / direction.length());
+        double phi = std::atan2(direction.x(), direction.z());
+        for (int frame = 0; frame < cam.animation_sample; frame++) {
+            cam.rotate(theta, phi);
+            cam.zoom(1.005);
+            cam.initialize();
+            g_anim.push_back(AnimFrame{camera_frame(cam), {}});
+            phi += delta_phi;
+            if (phi >= 2 * pi) phi -= 2 * pi;
+            theta -= 0.01;
+            if (theta <= 0) theta = 0;
+        }
+        write_anim(false);
+        return;
+    }
     cam.initialize();
     Flat f;
     f.world_root = f.add_node(&world);
@@ -492,7 +550,14 @@ int main(int argc, char **argv) {
     int frame = argc > 10 ? atoi(argv[10]) : 0;
     double aspect = double(W) / double(H); // cpuRenderer.cpp:437
     switch (scene) {
-    case 1: first_scene(W, aspect, spp, depth, false, 1, "x.ppm", use_bvh, false, 0); break;
+    case 1:
+        if (g_mode == "anim") { // the reference's own animation path, from the process's default rand() seed
+            first_scene(W, aspect, spp, depth, false, 1, "x.ppm", use_bvh, true, 1);
+            write_anim(true);
+            break;
+        }
+        first_scene(W, aspect, spp, depth, false, 1, "x.ppm", use_bvh, false, 0);
+        break;
     case 2: cornell_box(W, aspect, spp, depth, false, 1, "x.ppm", use_bvh, false, 0); break;
     case 3: final_scene(W, aspect, spp, depth, false, 1, "x.ppm", use_bvh, false, 0); break;
     case 4: mesh_scene(W, aspect, spp, depth, false, 1, "x.ppm", use_bvh, false, 0); break;

@@ -12,7 +12,7 @@ from . import abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librtamd_host.so")
 ASSET_DIR = os.path.join(_HERE, "assets")
-EXPORTS = ["rtamd_host_build_scene", "rtamd_host_scene_desc", "rtamd_host_scene_camera", "rtamd_host_scene_save",
+EXPORTS = ["rtamd_host_build_scene", "rtamd_host_scene_desc", "rtamd_host_scene_camera", "rtamd_host_scene_save", "rtamd_host_scene_animation",
            "rtamd_host_scene_free"]
 _lib = None
 
@@ -31,6 +31,8 @@ def load() -> C.CDLL:
         L.rtamd_host_scene_camera.argtypes = [C.c_void_p, C.c_void_p]
         L.rtamd_host_scene_save.restype = C.c_int
         L.rtamd_host_scene_save.argtypes = [C.c_void_p, C.c_char_p]
+        L.rtamd_host_scene_animation.restype = C.c_int
+        L.rtamd_host_scene_animation.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.rtamd_host_scene_free.restype = None
         L.rtamd_host_scene_free.argtypes = [C.c_void_p]
         _lib = L
@@ -45,8 +47,11 @@ def _copy(ptr, n, dt):
 
 
 def build_scene(scene: int, image_width: int, image_height: int, samples_per_pixel: int, max_depth: int,
-                use_bvh: bool = True, frame: int = 0, asset_dir: str | None = None) -> abi.Scene:
-    """Build reference scene `scene` (1..5) with the C++ scene API; the result carries the camera frame."""
+                use_bvh: bool = True, frame: int = 0, asset_dir: str | None = None,
+                animation: int | None = None) -> abi.Scene:
+    """Build reference scene `scene` (1..5) with the C++ scene API; the result carries the camera frame.  With
+    animation = 0 (rotate + zoom) or 1 (translate) it also carries `.animation`: the camera frames of
+    camera::render_animation (camera.h:46), one per frame."""
     L = load()
     h = L.rtamd_host_build_scene(scene, image_width, image_height, samples_per_pixel, max_depth, int(use_bvh), frame,
                                  (asset_dir or ASSET_DIR).encode())
@@ -60,6 +65,13 @@ def build_scene(scene: int, image_width: int, image_height: int, samples_per_pix
         cam = np.zeros(1, dtype=abi.camera_dtype)
         assert L.rtamd_host_scene_camera(h, cam.ctypes.data) == 0
         sc.camera = cam
+        if animation is not None:
+            n = L.rtamd_host_scene_animation(h, animation, None, 0)
+            if n < 0:
+                raise ValueError("rtamd_host_scene_animation: bad method")
+            cams = np.zeros(n, dtype=abi.camera_dtype)
+            assert L.rtamd_host_scene_animation(h, animation, cams.ctypes.data, n) == n
+            sc.animation = cams
     finally:
         L.rtamd_host_scene_free(h)
     return sc

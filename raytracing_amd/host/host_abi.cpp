@@ -8,6 +8,7 @@ struct rtamd_host_scene {
     rtamd::FlatScene flat;
     rt_scene_desc desc{};
     rt_camera cam{};
+    camera fresh; // the scene's camera as the scene function leaves it, before any initialize()
 };
 
 extern "C" {
@@ -26,6 +27,7 @@ rtamd_host_scene *rtamd_host_build_scene(int scene, int image_width, int image_h
     c.aspect_ratio = double(image_width) / double(image_height); // cpuRenderer.cpp:437
     c.samples_per_pixel = samples_per_pixel;
     c.max_depth = max_depth;
+    s->fresh = c;
     s->cam = c.frame();
     camera::flatten(s->built.world, s->built.lights, s->flat);
     s->desc = s->flat.desc();
@@ -38,6 +40,17 @@ int rtamd_host_scene_camera(const rtamd_host_scene *s, rt_camera *out) {
     if (!s || !out) return RT_ERR_INVALID;
     *out = s->cam;
     return RT_OK;
+}
+
+int rtamd_host_scene_animation(const rtamd_host_scene *s, int method, rt_camera *out, int cap) {
+    if (!s || method < 0 || method > 1) return RT_ERR_INVALID;
+    camera c = s->fresh; // every call replays the sequence from the scene function's camera
+    c.animation_method = method;
+    const int n = c.animation_frames();
+    if (!out) return n;
+    if (cap < n) return RT_ERR_INVALID;
+    for (int f = 0; f < n; f++) out[f] = c.animation_step(f);
+    return n;
 }
 
 int rtamd_host_scene_save(const rtamd_host_scene *s, const char *path) {

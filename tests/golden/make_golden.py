@@ -13,6 +13,11 @@ reference's own code (scene graphs, hit records, rendered pixel sums); no refere
   conv{N}.npz    48x27, depth 50 converged frame: mean of 5 (final_scene: 25) independent reference runs x 16900 spp
                  (srand 11..15 / 11..35); `runs` keeps the first five for the noise-floor estimate
                  -- optional, produced with --converged (about 25 core-minutes)
+  anim_translate.npz  what `cpuRayTracer 1 4 6 true <any> false true 1 24 16` produces: the reference's own
+                 first_scene(animation=true) -> camera::render_animation() run, single-threaded from the process's
+                 default rand() seed: camera frame and write_color ints of each of its 42 frames
+  anim_rotate.npz     camera frames of the 62-frame rotate + zoom sequence (camera.h:49-59,93-96; the reference's
+                 rotate()/zoom()/initialize() driven in that order by refgen), 24x16
 """
 import argparse
 import os
@@ -62,13 +67,40 @@ def read_img(path):
     return W, H, n, d, seed, sums, by
 
 
+def read_anim(path):
+    b = open(path, "rb").read()
+    assert b[:8] == b"RTANIM01"
+    n, W, H, with_images = (int(x) for x in np.frombuffer(b, "<i4", 4, 8))
+    off = 24
+    cams = np.frombuffer(b, abi.camera_dtype, n, off).copy()
+    off += n * abi.camera_dtype.itemsize
+    imgs = np.frombuffer(b, "<i4", n * W * H * 3, off).reshape(n, H, W, 3).copy() if with_images else None
+    return cams, imgs
+
+
+def make_anim():
+    refgen("anim", 1, 24, 16, 4, 6, 1, f"{OUT}/anim_translate.bin")
+    cams, imgs = read_anim(f"{OUT}/anim_translate.bin")
+    assert len(cams) == 42 and imgs.max() < 256
+    np.savez_compressed(f"{GOLD}/anim_translate.npz", cameras=cams.view("u1"), images=imgs.astype(np.uint8))
+    refgen("anim_rotate", 1, 24, 16, 4, 6, 1, f"{OUT}/anim_rotate.bin")
+    cams, _ = read_anim(f"{OUT}/anim_rotate.bin")
+    assert len(cams) == 62
+    np.savez_compressed(f"{GOLD}/anim_rotate.npz", cameras=cams.view("u1"))
+    print("animation fixtures: 42 translate frames (cameras + images), 62 rotate frames (cameras)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--converged", action="store_true", help="also (re)run the long converged renders")
     ap.add_argument("--scenes", default="1,2,3,4")
+    ap.add_argument("--anim-only", action="store_true", help="only (re)generate the animation fixtures")
     a = ap.parse_args()
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
     os.makedirs(OUT, exist_ok=True)
+    make_anim()
+    if a.anim_only:
+        return
     # extra graph shapes: one frame of the bounce animation (cpuRenderer.cpp:19) and a scene without BVH
     refgen("dump", 5, 64, 36, 9, 10, 1, f"{OUT}/scene5_f7.rtscene", 0, 7)
     abi.Scene.load(f"{OUT}/scene5_f7.rtscene").save_npz(f"{GOLD}/scene5_f7.npz")
