@@ -58,6 +58,10 @@ template <class R> class Flattener {
         f_.xforms.push_back(XformT<R>{}); // context 0 = world space
         rc = emit(d_.world_root, 0, 0);
         if (rc) return rc;
+        // end-of-stream sentinel: every skip link that leaves the last subtree lands here, and its header says
+        // "traversal finished", so a traversal step never needs a bounds check
+        const int end = push_units(2, -1);
+        f_.stream[end + 1].w[3] = I(make_hdr(K_READY, 0));
         return emit_lights();
     }
 
@@ -295,8 +299,8 @@ template <class R> class Flattener {
                 cvt_lo(n.bbox[2 * a], lo[a]);
                 cvt_hi(n.bbox[2 * a + 1], hi[a]);
             }
-            f_.stream[self] = UnitT<R>{{lo[0], lo[1], lo[2], hi[0]}};
-            f_.stream[self + 1] = UnitT<R>{{hi[1], hi[2], I(0), I(make_hdr(K_BOX, 0))}};
+            f_.stream[self] = UnitT<R>{{lo[0], hi[0], lo[1], hi[1]}};
+            f_.stream[self + 1] = UnitT<R>{{lo[2], hi[2], I(0), I(make_hdr(K_BOX, 0))}};
             int rc = emit(n.a, ctx, rdepth + 1);
             if (rc) return rc;
             if (n.b != n.a) { // span-1 nodes have left == right (bvh.h:30): the second visit cannot change the result
@@ -311,8 +315,8 @@ template <class R> class Flattener {
             int mat, face_id[6], outward;
             if (fuse_ && match_box(id, lo, hi, mat, face_id, outward)) {
                 const int off = push_units(2, id);
-                f_.stream[off] = UnitT<R>{{F(lo[0]), F(lo[1]), F(lo[2]), F(hi[0])}};
-                f_.stream[off + 1] = UnitT<R>{{F(hi[1]), F(hi[2]), I(mat), I(make_hdr(K_AABOX, outward))}};
+                f_.stream[off] = UnitT<R>{{F(lo[0]), F(hi[0]), F(lo[1]), F(hi[1])}};
+                f_.stream[off + 1] = UnitT<R>{{F(lo[2]), F(hi[2]), I(mat), I(make_hdr(K_AABOX, outward))}};
                 f_.cold[off] = UnitT<R>{{I(face_id[0]), I(face_id[1]), I(face_id[2]), I(face_id[3])}};
                 f_.cold[off + 1] = UnitT<R>{{I(face_id[4]), I(face_id[5]), I(0), I(0)}};
                 f_.n_fused_boxes++;

@@ -173,6 +173,7 @@ template <class R> RT_DEV int ldi(R x) { return dec_int(x); }
 // A unit always moves as whole 16-byte vectors (ds_read_b128 / global_load_dwordx4), never as scalar pieces.
 typedef float rt_f4 __attribute__((ext_vector_type(4)));
 typedef double rt_d2 __attribute__((ext_vector_type(2)));
+typedef float rt_f2 __attribute__((ext_vector_type(2)));
 RT_DEV UnitT<float> ld_unit(const UnitT<float> *p) {
     const rt_f4 v = *reinterpret_cast<const rt_f4 *>(p);
     return UnitT<float>{{v.x, v.y, v.z, v.w}};
@@ -231,13 +232,12 @@ template <class R> RT_DEV SceneT<R> stage_scene(const SceneT<R> &sc) {
 // float path computes the same slab distances and folds them with min/max.
 template <class R>
 RT_DEV bool box_hit(const UnitT<R> &u0, const UnitT<R> &u1, V3<R> o, V3<R> inv, R tmin, R tmax) {
-    const R bx0 = u0.w[0], by0 = u0.w[1], bz0 = u0.w[2], bx1 = u0.w[3], by1 = u1.w[0], bz1 = u1.w[1];
+    const R bx0 = u0.w[0], bx1 = u0.w[1], by0 = u0.w[2], by1 = u0.w[3], bz0 = u1.w[0], bz1 = u1.w[1];
     if constexpr (sizeof(R) == 4) {
-        R tx0 = (bx0 - o.x) * inv.x, tx1 = (bx1 - o.x) * inv.x;
-        R ty0 = (by0 - o.y) * inv.y, ty1 = (by1 - o.y) * inv.y;
-        R tz0 = (bz0 - o.z) * inv.z, tz1 = (bz1 - o.z) * inv.z;
-        R tn = m_max(m_max(m_min(tx0, tx1), m_min(ty0, ty1)), m_max(m_min(tz0, tz1), tmin));
-        R tf = m_min(m_min(m_max(tx0, tx1), m_max(ty0, ty1)), m_min(m_max(tz0, tz1), tmax));
+        // (min, max) pairs sit in adjacent registers: v_pk_add_f32 / v_pk_mul_f32 do both slab planes of an axis at once
+        const rt_f2 tx = (rt_f2{bx0, bx1} - o.x) * inv.x, ty = (rt_f2{by0, by1} - o.y) * inv.y, tz = (rt_f2{bz0, bz1} - o.z) * inv.z;
+        R tn = m_max(m_max(m_min(tx.x, tx.y), m_min(ty.x, ty.y)), m_max(m_min(tz.x, tz.y), tmin));
+        R tf = m_min(m_min(m_max(tx.x, tx.y), m_max(ty.x, ty.y)), m_min(m_max(tz.x, tz.y), tmax));
         return tf > tn;
     } else {
         {
@@ -266,9 +266,9 @@ RT_DEV bool box_hit(const UnitT<R> &u0, const UnitT<R> &u1, V3<R> o, V3<R> inv, 
 // surface at the slab entry and exit distances; quad::hit accepts tmin <= t <= tmax (interval::contains, quad.h:41).
 template <class R>
 RT_DEV bool aabox_t(const UnitT<R> &u0, const UnitT<R> &u1, V3<R> o, V3<R> inv, R tmin, R tmax, R &t_out) {
-    R tx0 = (u0.w[0] - o.x) * inv.x, tx1 = (u0.w[3] - o.x) * inv.x;
-    R ty0 = (u0.w[1] - o.y) * inv.y, ty1 = (u1.w[0] - o.y) * inv.y;
-    R tz0 = (u0.w[2] - o.z) * inv.z, tz1 = (u1.w[1] - o.z) * inv.z;
+    R tx0 = (u0.w[0] - o.x) * inv.x, tx1 = (u0.w[1] - o.x) * inv.x;
+    R ty0 = (u0.w[2] - o.y) * inv.y, ty1 = (u0.w[3] - o.y) * inv.y;
+    R tz0 = (u1.w[0] - o.z) * inv.z, tz1 = (u1.w[1] - o.z) * inv.z;
     R tn = m_max(m_max(m_min(tx0, tx1), m_min(ty0, ty1)), m_min(tz0, tz1));
     R tf = m_min(m_min(m_max(tx0, tx1), m_max(ty0, ty1)), m_max(tz0, tz1));
     if (!(tf >= tn)) return false;
@@ -413,25 +413,23 @@ template <class R> struct Trav {
     int best_off; // stream offset of the winning record, -1 = miss
     int best_ctx;
     int ctx;
-    int i; // cursor (unit offset); >= n_units: traversal finished
+    int i; // cursor (unit offset)
     // the record at the cursor
     UnitT<R> u0, u1;
     int hdr;
 };
 
-template <class R, bool ALL_LDS> RT_DEV void trav_goto(const Mem<R, ALL_LDS> &mem, int n_units, Trav<R> &tv, int i) {
+// Move the cursor.  No bounds check: the stream ends in a sentinel record whose header is K_READY ("traversal
+// finished"), and every skip link that leaves the last subtree points at it.
+template <class R, bool ALL_LDS> RT_DEV void trav_goto(const Mem<R, ALL_LDS> &mem, Trav<R> &tv, int i) {
     tv.i = i;
-    if (i < n_units) {
-        tv.u0 = mem.ld(i);
-        tv.u1 = mem.ld(i + 1);
-        tv.hdr = ldi(tv.u1.w[3]);
-    } else {
-        tv.hdr = K_READY; // traversal finished
-    }
+    tv.u0 = mem.ld(i);
+    tv.u1 = mem.ld(i + 1);
+    tv.hdr = ldi(tv.u1.w[3]);
 }
 
 template <class R, bool ALL_LDS>
-RT_DEV void trav_begin(const Mem<R, ALL_LDS> &mem, int n_units, Trav<R> &tv, const RayT<R> &world) {
+RT_DEV void trav_begin(const Mem<R, ALL_LDS> &mem, Trav<R> &tv, const RayT<R> &world) {
     tv.o = world.o;
     tv.d = world.d;
     tv.inv = inv_dir(world.d);
@@ -439,14 +437,14 @@ RT_DEV void trav_begin(const Mem<R, ALL_LDS> &mem, int n_units, Trav<R> &tv, con
     tv.best_off = -1;
     tv.best_ctx = 0;
     tv.ctx = 0;
-    trav_goto(mem, n_units, tv, 0);
+    trav_goto(mem, tv, 0);
 }
 
 // One BOX record: descend (next record) or take the skip link.
 template <class R, bool ALL_LDS>
-RT_DEV void trav_box_step(const Mem<R, ALL_LDS> &mem, int n_units, Trav<R> &tv, R tmin) {
+RT_DEV void trav_box_step(const Mem<R, ALL_LDS> &mem, Trav<R> &tv, R tmin) {
     const bool hit = box_hit(tv.u0, tv.u1, tv.o, tv.inv, tmin, tv.best_t);
-    trav_goto(mem, n_units, tv, hit ? tv.i + 2 : ldi(tv.u1.w[2]));
+    trav_goto(mem, tv, hit ? tv.i + 2 : ldi(tv.u1.w[2]));
 }
 
 // One non-BOX record.
@@ -505,7 +503,7 @@ RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, Trav
         tv.d = r.d;
         tv.inv = inv_dir(r.d);
     }
-    trav_goto(mem, sc.n_units, tv, next);
+    trav_goto(mem, tv, next);
 }
 
 template <class R> struct Hit { // hittable.h:10 hit_record
@@ -565,10 +563,10 @@ RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const Ra
             if (e < err) { err = e; face = f; }
         };
         probe(u0.w[0], r.o.x, inv.x, 0);
-        probe(u0.w[3], r.o.x, inv.x, 1);
-        probe(u0.w[1], r.o.y, inv.y, 2);
-        probe(u1.w[0], r.o.y, inv.y, 3);
-        probe(u0.w[2], r.o.z, inv.z, 4);
+        probe(u0.w[1], r.o.x, inv.x, 1);
+        probe(u0.w[2], r.o.y, inv.y, 2);
+        probe(u0.w[3], r.o.y, inv.y, 3);
+        probe(u1.w[0], r.o.z, inv.z, 4);
         probe(u1.w[1], r.o.z, inv.z, 5);
         const int axis = face >> 1;
         const R sgn = (face & 1) ? R(1) : R(-1); // outward direction of this face
@@ -1053,7 +1051,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                 depth = cam.max_depth;
                 if (depth > 0) { // camera.h:294
                     rays++;
-                    trav_begin(mem, n_units, tv, ray);
+                    trav_begin(mem, tv, ray);
                     return;
                 }
                 s++; // max_depth <= 0: the sample is black
@@ -1097,7 +1095,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                 bool at_box = is_box;
                 for (int rep = 0; rep < RT_BOX_REPEAT; rep++) {
                     if (at_box) {
-                        trav_box_step(mem, n_units, tv, tmin);
+                        trav_box_step(mem, tv, tmin);
                         at_box = (tv.hdr & 15) == K_BOX;
                     }
                     if (__popcll(__ballot(at_box)) < RT_BOX_REPEAT_MIN) break;
@@ -1108,13 +1106,13 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     if constexpr (sizeof(R) == 8) cc = cc + scale<R>(ray.tm, mk<R>(R(0), R(0), R(0))); // center.at(time), sphere.h:30
                     R t;
                     if (sphere_t(cc, tv.u0.w[3], tv.o, tv.d, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx; }
-                    trav_goto(mem, n_units, tv, tv.i + 2);
+                    trav_goto(mem, tv, tv.i + 2);
                 }
             } else if (action == A_AABOX) {
                 if (is_aab) {
                     R t;
                     if (aabox_t(tv.u0, tv.u1, tv.o, tv.inv, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx; }
-                    trav_goto(mem, n_units, tv, tv.i + 2);
+                    trav_goto(mem, tv, tv.i + 2);
                 }
             } else if (action == A_MEDIUM) {
                 if (is_med) {
@@ -1125,7 +1123,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                                  tv.best_t, mxi, t)) {
                         tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx;
                     }
-                    trav_goto(mem, n_units, tv, tv.i + 2);
+                    trav_goto(mem, tv, tv.i + 2);
                 }
             } else if (action == A_OTHER) {
                 if (is_oth) {
@@ -1155,7 +1153,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     }
                     if (alive) {
                         rays++;
-                        trav_begin(mem, n_units, tv, ray);
+                        trav_begin(mem, tv, ray);
                     } else {
                         ax += L.x; ay += L.y; az += L.z;
                         s++;
@@ -1225,9 +1223,9 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(SceneT<R> sc_arg, const rt
             return u01<R>(o0);
         };
         Trav<R> tv;
-        trav_begin(mem, sc.n_units, tv, r);
-        while (tv.i < sc.n_units) {
-            if ((tv.hdr & 15) == K_BOX) trav_box_step(mem, sc.n_units, tv, R(0.001));
+        trav_begin(mem, tv, r);
+        while ((tv.hdr & 15) != K_READY) {
+            if ((tv.hdr & 15) == K_BOX) trav_box_step(mem, tv, R(0.001));
             else trav_leaf_step(mem, sc, tv, r, R(0.001), mxi);
         }
         rt_hit o;

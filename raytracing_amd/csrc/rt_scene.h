@@ -13,14 +13,15 @@
 // workgroup; the remainder (large meshes) is read from global memory through L1/L2.
 //
 //   record            units  unit0                     unit1                              unit2..
-//   BOX     (bvh_node)   2   bmin.xyz, bmax.x          bmax.y, bmax.z, skip, hdr
+//   BOX     (bvh_node)   2   x.min, x.max, y.min, y.max   z.min, z.max, skip, hdr          (min/max pairs: packed f32 math)
 //   SPHERE / MSPHERE     2/3 c.xyz, radius             mat, -, -, hdr                     d.xyz (MSPHERE: centre = c + time*d)
-//   AABOX   (box())      2   bmin.xyz, bmax.x          bmax.y, bmax.z, mat, hdr(payload = 6 face-orientation bits)
+//   AABOX   (box())      2   x.min, x.max, y.min, y.max   z.min, z.max, mat, hdr(payload = 6 face-orientation bits)
 //   QUAD                 5   n.xyz, D                  Q.xyz, hdr                         u.xyz, mat | v.xyz, area | w.xyz, -
 //   TRI                  3   v0.xyz, e1.x              e1.y, e1.z, e2.x, hdr              e2.y, e2.z, mat, cull
 //   MEDIUM               2   c.xyz, radius (boundary)  -1/density, mat, node_id, hdr
 //   XF_ENTER             2   p0, p1, p2, -             xf kind, ctx id, -, hdr            (translate: offset; rotate_y: sin, cos)
 //   XF_EXIT              2   -                         -, parent ctx id, -, hdr
+//   (end)                2   -                         -, -, -, hdr = K_READY             sentinel behind the last record
 //
 // AABOX exists in the f32 stream only: a hittable_list of six axis-aligned quads that form a closed box with one
 // material (what box() of quad.h:103 builds) is fused into one slab test.  The f64 parity stream keeps the six quads.
@@ -36,7 +37,8 @@
 namespace rtamd {
 
 // Record kinds.  0..3 are the kinds that have a code block of their own in the render kernel's wave machine, >= 4 share
-// the "other" block; 14 / 15 never occur in the stream: they mark a lane's cursor as idle / past the end of the stream.
+// the "other" block; K_READY is the header of the end-of-stream sentinel (traversal finished: shade), K_IDLE never
+// occurs in the stream: it marks a lane without work.
 enum : int {
     K_BOX = 0,
     K_SPHERE = 1, // static sphere
