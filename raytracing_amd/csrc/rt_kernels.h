@@ -954,7 +954,18 @@ RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const CameraT
     return true;
 }
 
-template <class R> struct Accum { typedef R type; };
+// LDS accumulation of a finished path (ds_add_f32 / ds_add_f64; wave scope: only this wave touches its accumulators)
+template <class R> RT_DEV void lds_add(R *p, R v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+
+// Wave-uniform helpers that stay on the scalar unit: the lane mask of a predicate without the int round trip of
+// __ballot(), and its population count as two 32-bit s_bcnt1 (a 64-bit count is compared on the VALU).
+RT_DEV unsigned long long lane_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+RT_DEV int popc64(unsigned long long m) { return __builtin_popcount((unsigned)m) + __builtin_popcount((unsigned)(m >> 32)); }
+RT_DEV unsigned smax_u32(unsigned a, unsigned b) { // the compiler's own choice for a uniform max chain is v_max3_u32 + readfirstlane
+    unsigned r;
+    asm("s_max_u32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc");
+    return r;
+}
 
 enum : int { RT_MAX_SCHED_CHUNKS = 24 };
 // Scheduling constants of the render kernel's wave machine (tuned on final_scene 1080p, tools/sweep.py history in
@@ -999,15 +1010,18 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     const int lane = threadIdx.x & 63;
     const int n_tiles = a.tiles_x * a.tiles_y;
     const int n_items = n_tiles * a.n_chunks;
-    const int n_units = sc.n_units;
     const R tmin = R(0.001);
+    const float cam_recip_n = 1.0f / (float)cam.sqrt_spp;
+    // this wave's pixel accumulators: 64 x RGB behind the scene's LDS image
+    R *const acc = reinterpret_cast<R *>(rt_smem + (size_t)sc_arg.lds_units * sizeof(UnitT<R>) + (sc_arg.tab_in_lds ? (size_t)sc_arg.tab_bytes : 0)) +
+                   (threadIdx.x >> 6) * 192;
     unsigned rays = 0;
     const uint32_t k0 = a.k0, k1 = a.k1;
 #ifdef RT_PROFILE_ACTIONS
     unsigned long long prof_cyc[A_COUNT] = {}, prof_trips[A_COUNT] = {}, prof_lanes[A_COUNT] = {};
     const unsigned long long t_wave0 = __builtin_amdgcn_s_memtime();
     ShadeProf sp{};
-    unsigned long long sp_tail = 0;
+    unsigned long long sp_tail = 0, prof_idle = 0, prof_ready = 0, prof_all = 0;
 #endif
     for (;;) {
         int item = 0;
@@ -1016,50 +1030,70 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
         if (item >= n_items) break;
         const int chunk = item / n_tiles, tile = item - chunk * n_tiles;
         const int tj = tile / a.tiles_x, ti = tile - tj * a.tiles_x;
-        const int i = ti * 8 + (lane & 7), j = tj * 8 + (lane >> 3);
-        const bool inside = (i < cam.W) && (j < cam.H);
-        int s, s_end;
+        int s0, s1;
         if (a.chunk_size > 0) {
-            s = a.s_begin + chunk * a.chunk_size;
-            s_end = s + a.chunk_size;
-            if (s_end > a.s_end) s_end = a.s_end;
+            s0 = a.s_begin + chunk * a.chunk_size;
+            s1 = s0 + a.chunk_size;
+            if (s1 > a.s_end) s1 = a.s_end;
         } else {
-            s = a.chunk_start[chunk];
-            s_end = a.chunk_start[chunk + 1];
+            s0 = a.chunk_start[chunk];
+            s1 = a.chunk_start[chunk + 1];
         }
-        if (!inside) s = s_end;
-        const uint32_t pixel = (uint32_t)(j * cam.W + i);
-        // per-pixel sum over the samples of this item (<= a few hundred; the reference sums in double: camera.h:175-181;
-        // the float path sums an item in float and the items of a pixel in double, reduce_chunks_kernel)
-        typename Accum<R>::type ax = 0, ay = 0, az = 0;
+        // The item's work units: unit u = sample s0 + u / 64 of the tile's pixel u % 64.  Lanes do not own pixels: a lane
+        // whose path has ended takes the next unit (wave-level dealing: rank among the asking lanes + a scalar cursor),
+        // so a pixel with short paths never leaves its lane idle while a neighbour grinds through long ones.  The RNG
+        // is keyed by (pixel, sample), so the image does not depend on who traces what; a finished path is added to the
+        // wave's 64-pixel accumulator in LDS (ds_add: the order of the adds is this wave's own deterministic schedule).
+        const int n_item_units = (s1 - s0) << 6;
+        int next_unit = 0;
+        acc[lane * 3] = R(0); acc[lane * 3 + 1] = R(0); acc[lane * 3 + 2] = R(0);
         RayT<R> ray;
         V3<R> beta;
         Trav<R> tv;
-        tv.i = n_units;
+        tv.i = 0;
         tv.hdr = K_IDLE;
         int depth = 0;
+        int u = 0;          // the unit this lane works on
+        uint32_t pixel = 0; // its pixel (row-major index in the image)
 
-        // start the next camera path of this lane (or retire the lane)
-        auto next_path = [&]() {
-            while (s < s_end) {
-                Rng<R> g;
-                g.k0 = k0;
-                g.k1 = k1;
-                g.begin(pixel, (uint32_t)s);
-                ray = get_ray(cam, i, j, s % cam.sqrt_spp, s / cam.sqrt_spp, g);
-                beta = mk<R>(R(1), R(1), R(1));
-                depth = cam.max_depth;
-                if (depth > 0) { // camera.h:294
-                    rays++;
-                    trav_begin(mem, tv, ray);
-                    return;
+        // hand new units to the lanes that ask (call at wave-converged points only)
+        auto deal = [&](bool need) {
+            unsigned long long m = lane_mask(need);
+            while (m) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (need) {
+                    const int un = next_unit + rank;
+                    if (un >= n_item_units) {
+                        need = false; // the item has no units left: the lane idles until the wave's last path ends
+                    } else {
+                        const int p = un & 63;
+                        const int i = ti * 8 + (p & 7), j = tj * 8 + (p >> 3);
+                        if (i < cam.W && j < cam.H) { // (units of pixels beyond the image edge are skipped)
+                            need = false;
+                            u = un;
+                            pixel = (uint32_t)(j * cam.W + i);
+                            const int s = s0 + (un >> 6);
+                            int sj = (int)((float)s * cam_recip_n); // s / sqrt_spp, s % sqrt_spp without an integer division
+                            int si = s - sj * cam.sqrt_spp;
+                            if (si < 0) { sj--; si += cam.sqrt_spp; }
+                            if (si >= cam.sqrt_spp) { sj++; si -= cam.sqrt_spp; }
+                            Rng<R> g;
+                            g.k0 = k0;
+                            g.k1 = k1;
+                            g.begin(pixel, (uint32_t)s);
+                            ray = get_ray(cam, i, j, si, sj, g);
+                            beta = mk<R>(R(1), R(1), R(1));
+                            depth = cam.max_depth;
+                            rays++;
+                            trav_begin(mem, tv, ray);
+                        }
+                    }
                 }
-                s++; // max_depth <= 0: the sample is black
+                next_unit += popc64(m);
+                m = lane_mask(need);
             }
-            tv.i = n_units;
-            tv.hdr = K_IDLE;
         };
-        next_path();
+        if (cam.max_depth > 0) deal(true); // max_depth <= 0: every sample is black (camera.h:294), the sums stay zero
 
         for (;;) {
             // lane state = low bits of tv.hdr: the kind of the record at the cursor, K_READY (traversal finished, waiting to
@@ -1068,37 +1102,39 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             const bool is_box = kind == K_BOX, is_sph = kind == K_SPHERE, is_aab = kind == K_AABOX, is_med = kind == K_MEDIUM;
             const bool is_oth = kind >= K_QUAD && kind < K_IDLE; // quad, triangle, moving sphere, instance boundary
             const bool ready = kind == K_READY;
-            const unsigned long long mb = __ballot(is_box), ms = __ballot(is_sph), ma = __ballot(is_aab), mm = __ballot(is_med),
-                                     mo = __ballot(is_oth), mr = __ballot(ready);
+            const unsigned long long mb = lane_mask(is_box), ms = lane_mask(is_sph), ma = lane_mask(is_aab), mm = lane_mask(is_med),
+                                     mo = lane_mask(is_oth), mr = lane_mask(ready);
             if (!(mb | ms | ma | mm | mo | mr)) break;
             // Run ONE block per trip: shading once enough lanes wait for it, else the record kind with the largest weighted
             // number of waiting lanes (score = count * weight, block id in the low bits -> one max chain).
-            const int nr = __popcll(mr);
+            const int nr = popc64(mr);
             int action = A_SHADE;
             if (nr < RT_SHADE_T) {
-                const unsigned sb = ((unsigned)(__popcll(mb) * RT_W_BOX) << 3) | A_BOX, ss = ((unsigned)(__popcll(ms) * RT_W_LEAF) << 3) | A_SPHERE,
-                               sa = ((unsigned)(__popcll(ma) * RT_W_LEAF) << 3) | A_AABOX, sm = ((unsigned)(__popcll(mm) * RT_W_LEAF) << 3) | A_MEDIUM,
-                               so = ((unsigned)(__popcll(mo) * RT_W_LEAF) << 3) | A_OTHER;
-                unsigned best = sb > ss ? sb : ss;
-                best = best > sa ? best : sa;
-                best = best > sm ? best : sm;
-                best = best > so ? best : so;
+                const unsigned sb = ((unsigned)(popc64(mb) * RT_W_BOX) << 3) | A_BOX, ss = ((unsigned)(popc64(ms) * RT_W_LEAF) << 3) | A_SPHERE,
+                               sa = ((unsigned)(popc64(ma) * RT_W_LEAF) << 3) | A_AABOX, sm = ((unsigned)(popc64(mm) * RT_W_LEAF) << 3) | A_MEDIUM,
+                               so = ((unsigned)(popc64(mo) * RT_W_LEAF) << 3) | A_OTHER;
+                const unsigned best = smax_u32(smax_u32(smax_u32(sb, ss), smax_u32(sa, sm)), so);
                 if (best >= 8u) action = (int)(best & 7u);
             }
 #ifdef RT_PROFILE_ACTIONS
             const unsigned long long t_a = __builtin_amdgcn_s_memtime();
-            const int n_act = action == A_BOX ? __popcll(mb) : action == A_SPHERE ? __popcll(ms) : action == A_AABOX ? __popcll(ma)
-                              : action == A_MEDIUM ? __popcll(mm) : action == A_OTHER ? __popcll(mo) : nr;
+            prof_idle += 64 - popc64(mb | ms | ma | mm | mo | mr);
+            prof_ready += nr;
+            prof_all += 1;
+            const int n_act = action == A_BOX ? popc64(mb) : action == A_SPHERE ? popc64(ms) : action == A_AABOX ? popc64(ma)
+                              : action == A_MEDIUM ? popc64(mm) : action == A_OTHER ? popc64(mo) : nr;
 #endif
             if (action == A_BOX) {
                 // a few BOX steps in a row while enough lanes stay at BOX records (amortises the block selection)
+                // (a BOX header is the integer 0: kind 0, no payload; the header is re-read behind the join so that one
+                // compare per step serves both the next step's lane mask and the repeat decision)
                 bool at_box = is_box;
                 for (int rep = 0; rep < RT_BOX_REPEAT; rep++) {
-                    if (at_box) {
-                        trav_box_step(mem, tv, tmin);
-                        at_box = (tv.hdr & 15) == K_BOX;
-                    }
-                    if (__popcll(__ballot(at_box)) < RT_BOX_REPEAT_MIN) break;
+                    if (at_box) trav_box_step(mem, tv, tmin);
+                    int h = tv.hdr;
+                    asm volatile("" : "+v"(h));
+                    at_box = h == make_hdr(K_BOX, 0);
+                    if (popc64(lane_mask(at_box)) < RT_BOX_REPEAT_MIN) break;
                 }
             } else if (action == A_SPHERE) {
                 if (is_sph) {
@@ -1117,7 +1153,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             } else if (action == A_MEDIUM) {
                 if (is_med) {
                     const int bounce_idx = cam.max_depth - depth;
-                    auto mxi = [&](int node_id) { return medium_draw<R>(k0, k1, pixel, (uint32_t)s, node_id, bounce_idx); };
+                    auto mxi = [&](int node_id) { return medium_draw<R>(k0, k1, pixel, (uint32_t)(s0 + (u >> 6)), node_id, bounce_idx); };
                     R t;
                     if (medium_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], tv.u1.w[0], ldi(tv.u1.w[2]), tv.o, tv.d, tmin,
                                  tv.best_t, mxi, t)) {
@@ -1128,10 +1164,11 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             } else if (action == A_OTHER) {
                 if (is_oth) {
                     const int bounce_idx = cam.max_depth - depth;
-                    auto mxi = [&](int node_id) { return medium_draw<R>(k0, k1, pixel, (uint32_t)s, node_id, bounce_idx); };
+                    auto mxi = [&](int node_id) { return medium_draw<R>(k0, k1, pixel, (uint32_t)(s0 + (u >> 6)), node_id, bounce_idx); };
                     trav_leaf_step(mem, sc, tv, ray, tmin, mxi);
                 }
             } else {
+                bool ended = false;
                 if (ready) {
 #ifdef RT_PROFILE_ACTIONS
                     sp.last = __builtin_amdgcn_s_memtime();
@@ -1139,7 +1176,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     Rng<R> g;
                     g.k0 = k0;
                     g.k1 = k1;
-                    g.begin_bounce(pixel, (uint32_t)s, cam.max_depth - depth);
+                    g.begin_bounce(pixel, (uint32_t)(s0 + (u >> 6)), cam.max_depth - depth);
                     RT_STAMP(0);
                     V3<R> L;
                     bool alive = shade(mem, sc, cam, ray, tv.best_t, tv.best_off, tv.best_ctx, beta, L, g RT_SP_ARG);
@@ -1155,17 +1192,19 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         rays++;
                         trav_begin(mem, tv, ray);
                     } else {
-                        ax += L.x; ay += L.y; az += L.z;
-                        s++;
-                        next_path();
+                        R *const px = acc + (u & 63) * 3;
+                        lds_add(px, L.x); lds_add(px + 1, L.y); lds_add(px + 2, L.z);
+                        tv.hdr = K_IDLE;
+                        ended = true;
                     }
-#ifdef RT_PROFILE_ACTIONS
-                    {
-                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                        sp_tail += __builtin_amdgcn_s_memtime() - sp.last;
-                    }
-#endif
                 }
+                deal(ended);
+#ifdef RT_PROFILE_ACTIONS
+                {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    sp_tail += __builtin_amdgcn_s_memtime() - sp.last;
+                }
+#endif
             }
 #ifdef RT_PROFILE_ACTIONS
             { // diagnostic build only: cycles, trips and active lanes per action -> counters[4 + 3*action ...]
@@ -1177,9 +1216,13 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             }
 #endif
         }
-        if (inside) {
-            size_t o = ((size_t)chunk * cam.H * cam.W + (size_t)j * cam.W + i) * 3;
-            out[o] = (float)ax; out[o + 1] = (float)ay; out[o + 2] = (float)az;
+        { // every path of the item has ended: lane p stores pixel p's sums (this wave's own ds_adds, in program order)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int i = ti * 8 + (lane & 7), j = tj * 8 + (lane >> 3);
+            if (i < cam.W && j < cam.H) {
+                size_t o = ((size_t)chunk * cam.H * cam.W + (size_t)j * cam.W + i) * 3;
+                out[o] = (float)acc[lane * 3]; out[o + 1] = (float)acc[lane * 3 + 1]; out[o + 2] = (float)acc[lane * 3 + 2];
+            }
         }
     }
     // wave-level ray count -> one atomic per wave
@@ -1195,6 +1238,9 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
         atomicAdd(&counters[3], __builtin_amdgcn_s_memtime() - t_wave0);
         for (int k = 0; k < 8; k++) atomicAdd(&counters[24 + k], sp.sec[k]);
         atomicAdd(&counters[32], sp_tail);
+        atomicAdd(&counters[33], prof_idle);
+        atomicAdd(&counters[34], prof_ready);
+        atomicAdd(&counters[35], prof_all);
     }
 #endif
 }

@@ -36,12 +36,12 @@ hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const Rende
     hipError_t e;
     if (sc.lds_units == sc.n_units) {
         auto k = render_kernel<R, true, C::block>;
-        if ((e = allow_lds(k, C::lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, block, lds, stream, sc, cam, a, out, counters);
+        if ((e = allow_lds(k, C::lds_bytes + C::accum_bytes)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, block, lds + C::accum_bytes, stream, sc, cam, a, out, counters);
     } else {
         auto k = render_kernel<R, false, C::block>;
-        if ((e = allow_lds(k, C::lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, block, lds, stream, sc, cam, a, out, counters);
+        if ((e = allow_lds(k, C::lds_bytes + C::accum_bytes)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, block, lds + C::accum_bytes, stream, sc, cam, a, out, counters);
     }
     return hipGetLastError();
 }

@@ -10,6 +10,7 @@ mkdir -p $OUT
 i=0
 while read -r grp; do
   [ -z "$grp" ] && continue
+  [ "$i" -ge "${PMC_PASSES:-99}" ] && break   # PMC_PASSES=1: only the VALU / wave-cycle group
   i=$((i+1))
   timeout -s KILL 240 rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -o p$i -- python3 bench.py $ARGS > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; exit 1; }
 done <<'GRP'
