@@ -335,7 +335,7 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
         rl.chunk_size = (n_samples + n_chunks - 1) / n_chunks;
         n_chunks = (n_samples + rl.chunk_size - 1) / rl.chunk_size;
     } else {
-        const int min_chunk = ctx->min_chunk > 0 ? ctx->min_chunk : 16;
+        const int min_chunk = ctx->min_chunk > 0 ? ctx->min_chunk : (n_samples >= 360 ? 32 : 16);
         const int divisor = ctx->chunk_divisor > 1 ? ctx->chunk_divisor : (n_samples >= 360 ? 3 : 2); // measured on final_scene 1080p
         rl.chunk_size = 0;
         n_chunks = 0;
@@ -392,8 +392,8 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
             const char *nm[9] = {"rng begin", "finalize", "material+emit", "metal", "dielectric", "texture", "sample dir", "pdfs+weight", "tail (trav_begin / next_path)"};
             for (int k = 0; k < 9; k++)
                 std::fprintf(stderr, "[rt_amd profile]   shade/%-30s %.1f%% of wave time\n", nm[k], 100.0 * (double)c[24 + k] / (double)(c[3] ? c[3] : 1));
-            std::fprintf(stderr, "[rt_amd profile] per trip: %.1f lanes idle (item tail), %.1f lanes waiting for shading, of 64\n",
-                         (double)c[33] / (double)(c[35] ? c[35] : 1), (double)c[34] / (double)(c[35] ? c[35] : 1));
+            std::fprintf(stderr, "[rt_amd profile] per trip: %.1f lanes idle (item tail), %.1f lanes waiting for shading, of 64; %.1f%% of trips after the item's last unit was dealt\n",
+                         (double)c[33] / (double)(c[35] ? c[35] : 1), (double)c[34] / (double)(c[35] ? c[35] : 1), 100.0 * (double)c[36] / (double)(c[35] ? c[35] : 1));
         }
         stats->samples = (uint64_t)n_px * (uint64_t)n_samples;
         stats->rays = rays;

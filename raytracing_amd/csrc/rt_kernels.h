@@ -187,7 +187,7 @@ template <class R, bool ALL_LDS> struct Mem {
     const UnitT<R> *glob;
     int lds_units;
     RT_DEV UnitT<R> ld(int off) const {
-        const UnitT<R> *l = reinterpret_cast<const UnitT<R> *>(rt_smem);
+        const UnitT<R> *l = reinterpret_cast<const UnitT<R> *>(rt_smem + LdsLayout<R>::stream_off);
         if constexpr (ALL_LDS) {
             return ld_unit(l + off);
         } else {
@@ -206,11 +206,11 @@ template <class R, bool ALL_LDS> struct Mem {
 // Stage the stream prefix (and, when it fits, the shading tables) into LDS; returns the scene whose table pointers
 // address the LDS copies (generic pointers: flat loads resolve them).
 template <class R> RT_DEV SceneT<R> stage_scene(const SceneT<R> &sc) {
-    UnitT<R> *l = reinterpret_cast<UnitT<R> *>(rt_smem);
+    UnitT<R> *l = reinterpret_cast<UnitT<R> *>(rt_smem + LdsLayout<R>::stream_off);
     for (int k = threadIdx.x; k < sc.lds_units; k += blockDim.x) l[k] = sc.stream[k];
     SceneT<R> o = sc;
     if (sc.tab_in_lds) {
-        unsigned char *dst = rt_smem + (size_t)sc.lds_units * sizeof(UnitT<R>);
+        unsigned char *dst = rt_smem + LdsLayout<R>::stream_off + (size_t)sc.lds_units * sizeof(UnitT<R>);
         const rt_f4 *src = reinterpret_cast<const rt_f4 *>(sc.tab);
         rt_f4 *d4 = reinterpret_cast<rt_f4 *>(dst);
         for (int k = threadIdx.x; k < sc.tab_bytes / 16; k += blockDim.x) d4[k] = src[k];
@@ -975,10 +975,10 @@ enum : int { RT_MAX_SCHED_CHUNKS = 24 };
 #define RT_W_BOX 2
 #endif
 #ifndef RT_W_LEAF
-#define RT_W_LEAF 4
+#define RT_W_LEAF 8
 #endif
 #ifndef RT_SHADE_T
-#define RT_SHADE_T 24
+#define RT_SHADE_T 40
 #endif
 #ifndef RT_BOX_REPEAT
 #define RT_BOX_REPEAT 12
@@ -1002,109 +1002,160 @@ enum : int { A_BOX = 0, A_SPHERE = 1, A_AABOX = 2, A_MEDIUM = 3, A_OTHER = 4, A_
 // a BOX record, at a leaf record, or waiting to be shaded; each trip of the loop runs ONE of the three code blocks,
 // chosen wave-uniformly, so the hot BOX step is never serialised behind leaf or shading code that only a few lanes
 // need (64-lane divergence is the limiter of this workload: see DESIGN.md, profiles/).
+// The kernel's uniform arguments, parked in LDS (LdsLayout::cold_bytes at offset 0) and read where they are needed:
+// held in scalar registers they would be live across the traversal loops, and the register allocator answers that with
+// v_writelane / v_readlane spill chains inside those loops.
+template <class R> struct ColdT {
+    SceneT<R> sc; // table pointers already rebased to their LDS copies
+    CameraT<R> cam;
+    RenderArgs a;
+};
+// per-wave item state (16 ints behind the wave's accumulators)
+enum : int { WS_CUR_I0 = 0, WS_CUR_J0, WS_CUR_CHUNK, WS_CUR_S0, WS_N_UNITS, WS_NEXT_UNIT, WS_CUR_SLOT, WS_PREV_I0, WS_PREV_J0,
+             WS_PREV_CHUNK, WS_CUR_VALID, WS_PREV_VALID, WS_MORE_ITEMS };
+
 template <class R, bool ALL_LDS, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT<R> cam, RenderArgs a, float *__restrict__ out,
+__global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT<R> cam_arg, RenderArgs a_arg, float *__restrict__ out,
                                                        unsigned long long *__restrict__ counters) {
+    static_assert(BLOCK == LdsLayout<R>::block, "LDS layout");
     const SceneT<R> sc = stage_scene(sc_arg);
+    const CameraT<R> &cam = cam_arg;
+    const RenderArgs &a = a_arg;
     const Mem<R, ALL_LDS> mem{sc.stream, sc.lds_units};
     const int lane = threadIdx.x & 63;
-    const int n_tiles = a.tiles_x * a.tiles_y;
-    const int n_items = n_tiles * a.n_chunks;
     const R tmin = R(0.001);
-    const float cam_recip_n = 1.0f / (float)cam.sqrt_spp;
-    // this wave's pixel accumulators: 64 x RGB behind the scene's LDS image
-    R *const acc = reinterpret_cast<R *>(rt_smem + (size_t)sc_arg.lds_units * sizeof(UnitT<R>) + (sc_arg.tab_in_lds ? (size_t)sc_arg.tab_bytes : 0)) +
-                   (threadIdx.x >> 6) * 192;
+    // this wave's accumulators (two slots = items in flight, x 64 pixels x RGB) and item state
+    R *const acc = reinterpret_cast<R *>(rt_smem + LdsLayout<R>::wave_off + (threadIdx.x >> 6) * LdsLayout<R>::wave_stride);
+    int *const ws = reinterpret_cast<int *>(acc + LdsLayout<R>::wave_acc);
     unsigned rays = 0;
-    const uint32_t k0 = a.k0, k1 = a.k1;
 #ifdef RT_PROFILE_ACTIONS
     unsigned long long prof_cyc[A_COUNT] = {}, prof_trips[A_COUNT] = {}, prof_lanes[A_COUNT] = {};
     const unsigned long long t_wave0 = __builtin_amdgcn_s_memtime();
     ShadeProf sp{};
-    unsigned long long sp_tail = 0, prof_idle = 0, prof_ready = 0, prof_all = 0;
+    unsigned long long sp_tail = 0, prof_idle = 0, prof_ready = 0, prof_all = 0, prof_tail = 0;
 #endif
-    for (;;) {
-        int item = 0;
-        if (lane == 0) item = (int)atomicAdd(&counters[1], 1ull);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= n_items) break;
-        const int chunk = item / n_tiles, tile = item - chunk * n_tiles;
-        const int tj = tile / a.tiles_x, ti = tile - tj * a.tiles_x;
-        int s0, s1;
-        if (a.chunk_size > 0) {
-            s0 = a.s_begin + chunk * a.chunk_size;
-            s1 = s0 + a.chunk_size;
-            if (s1 > a.s_end) s1 = a.s_end;
-        } else {
-            s0 = a.chunk_start[chunk];
-            s1 = a.chunk_start[chunk + 1];
+    // Work: an item = (8x8 pixel tile, chunk of the sample range) = 64 x samples UNITS, unit u = sample s0 + u / 64 of the
+    // tile's pixel u % 64.  Lanes do not own pixels: a lane whose path has ended takes the next unit (wave-level dealing:
+    // rank among the asking lanes + the wave's cursor), so a pixel with short paths never leaves its lane idle while a
+    // neighbour grinds through long ones; when the item has no units left the wave fetches the next item and keeps
+    // dealing while the old item's last paths finish (two items in flight: `cur` deals, `prev` drains).  The RNG is keyed
+    // by (pixel, sample), so the image does not depend on who traces what; a finished path is added to its item's
+    // 64-pixel accumulator in LDS (ds_add: the order of the adds is this wave's own deterministic schedule).
+    for (int k = 0; k < 6; k++) acc[lane + 64 * k] = R(0);
+    if (lane < 16) ws[lane] = 0;
+    RayT<R> ray;
+    V3<R> beta;
+    Trav<R> tv;
+    tv.i = 0;
+    tv.hdr = K_IDLE;
+    int bounce = 0;     // index of the ray this lane traces within its path (0 = camera ray)
+    int smp = 0;        // the unit this lane works on: sample index,
+    int pp = 0;         //   pixel within the tile | accumulator slot << 6,
+    uint32_t pixel = 0; //   pixel within the image (row-major)
+    auto wsl = [&](int k) { return __builtin_amdgcn_readfirstlane(ws[k]); };
+    int units_left = 0; // of the current item; -1: the item cursor is exhausted (wave-uniform, the only item state in a register)
+
+    // every path of an item has ended: lane p stores pixel p's sums and clears the accumulator for its next item
+    auto flush = [&](int slot, int i0, int j0, int chunk) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        R *const b = acc + slot * 192 + lane * 3;
+        const int i = i0 + (lane & 7), j = j0 + (lane >> 3);
+        if (i < cam.W && j < cam.H) {
+            const size_t o = ((size_t)chunk * cam.H * cam.W + (size_t)j * cam.W + i) * 3;
+            out[o] = (float)b[0]; out[o + 1] = (float)b[1]; out[o + 2] = (float)b[2];
         }
-        // The item's work units: unit u = sample s0 + u / 64 of the tile's pixel u % 64.  Lanes do not own pixels: a lane
-        // whose path has ended takes the next unit (wave-level dealing: rank among the asking lanes + a scalar cursor),
-        // so a pixel with short paths never leaves its lane idle while a neighbour grinds through long ones.  The RNG
-        // is keyed by (pixel, sample), so the image does not depend on who traces what; a finished path is added to the
-        // wave's 64-pixel accumulator in LDS (ds_add: the order of the adds is this wave's own deterministic schedule).
-        const int n_item_units = (s1 - s0) << 6;
-        int next_unit = 0;
-        acc[lane * 3] = R(0); acc[lane * 3 + 1] = R(0); acc[lane * 3 + 2] = R(0);
-        RayT<R> ray;
-        V3<R> beta;
-        Trav<R> tv;
-        tv.i = 0;
-        tv.hdr = K_IDLE;
-        int depth = 0;
-        int u = 0;          // the unit this lane works on
-        uint32_t pixel = 0; // its pixel (row-major index in the image)
+        b[0] = R(0); b[1] = R(0); b[2] = R(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    };
 
-        // hand new units to the lanes that ask (call at wave-converged points only)
-        auto deal = [&](bool need) {
-            unsigned long long m = lane_mask(need);
-            while (m) {
-                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (need) {
-                    const int un = next_unit + rank;
-                    if (un >= n_item_units) {
-                        need = false; // the item has no units left: the lane idles until the wave's last path ends
-                    } else {
-                        const int p = un & 63;
-                        const int i = ti * 8 + (p & 7), j = tj * 8 + (p >> 3);
-                        if (i < cam.W && j < cam.H) { // (units of pixels beyond the image edge are skipped)
-                            need = false;
-                            u = un;
-                            pixel = (uint32_t)(j * cam.W + i);
-                            const int s = s0 + (un >> 6);
-                            int sj = (int)((float)s * cam_recip_n); // s / sqrt_spp, s % sqrt_spp without an integer division
-                            int si = s - sj * cam.sqrt_spp;
-                            if (si < 0) { sj--; si += cam.sqrt_spp; }
-                            if (si >= cam.sqrt_spp) { sj++; si -= cam.sqrt_spp; }
-                            Rng<R> g;
-                            g.k0 = k0;
-                            g.k1 = k1;
-                            g.begin(pixel, (uint32_t)s);
-                            ray = get_ray(cam, i, j, si, sj, g);
-                            beta = mk<R>(R(1), R(1), R(1));
-                            depth = cam.max_depth;
-                            rays++;
-                            trav_begin(mem, tv, ray);
-                        }
-                    }
-                }
-                next_unit += popc64(m);
-                m = lane_mask(need);
-            }
-        };
-        if (cam.max_depth > 0) deal(true); // max_depth <= 0: every sample is black (camera.h:294), the sums stay zero
-
-        for (;;) {
+    for (;;) {
+        {
             // lane state = low bits of tv.hdr: the kind of the record at the cursor, K_READY (traversal finished, waiting to
-            // be shaded) or K_IDLE (no samples left in this item)
+            // be shaded) or K_IDLE (no unit)
             const int kind = tv.hdr & 15;
+            const unsigned long long midle = lane_mask(kind == K_IDLE);
+            if (midle && units_left >= 0) {
+                if (units_left > 0) {
+                    // deal units to the idle lanes: rank among the asking lanes + the item's cursor
+                    const int cur_i0 = wsl(WS_CUR_I0), cur_j0 = wsl(WS_CUR_J0), cur_s0 = wsl(WS_CUR_S0), n_item_units = wsl(WS_N_UNITS);
+                    const int slot6 = wsl(WS_CUR_SLOT) << 6;
+                    int next_unit = n_item_units - units_left;
+                    bool need = kind == K_IDLE;
+                    unsigned long long m = midle;
+                    do {
+                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        const int un = next_unit + rank;
+                        if (need && un < n_item_units) {
+                            const int p = un & 63;
+                            const int i = cur_i0 + (p & 7), j = cur_j0 + (p >> 3);
+                            if (i < cam.W && j < cam.H) { // (units of pixels beyond the image edge are skipped)
+                                need = false;
+                                pp = p | slot6;
+                                pixel = (uint32_t)(j * cam.W + i);
+                                smp = cur_s0 + (un >> 6);
+                                int sj = (int)((float)smp * (float)cam.recip_sqrt_spp); // s / sqrt_spp, s % sqrt_spp without an integer division
+                                int si = smp - sj * cam.sqrt_spp;
+                                if (si < 0) { sj--; si += cam.sqrt_spp; }
+                                if (si >= cam.sqrt_spp) { sj++; si -= cam.sqrt_spp; }
+                                Rng<R> g;
+                                g.k0 = a.k0;
+                                g.k1 = a.k1;
+                                g.begin(pixel, (uint32_t)smp);
+                                ray = get_ray(cam, i, j, si, sj, g);
+                                beta = mk<R>(R(1), R(1), R(1));
+                                bounce = 0;
+                                rays++;
+                                trav_begin(mem, tv, ray);
+                            }
+                        }
+                        next_unit += popc64(m);
+                        m = lane_mask(need);
+                    } while (m && next_unit < n_item_units);
+                    units_left = next_unit < n_item_units ? n_item_units - next_unit : 0;
+                    continue;
+                }
+                // the current item has no units left: once `prev` has drained, store it, make `cur` the new `prev`, fetch an item
+                const int cur_slot = wsl(WS_CUR_SLOT);
+                const bool prev_valid = wsl(WS_PREV_VALID) != 0;
+                if (!(prev_valid && lane_mask(kind != K_IDLE && (pp >> 6) != cur_slot))) {
+                    if (prev_valid) flush(cur_slot ^ 1, wsl(WS_PREV_I0), wsl(WS_PREV_J0), wsl(WS_PREV_CHUNK));
+                    int item = 0;
+                    if (lane == 0) item = (int)atomicAdd(&counters[1], 1ull);
+                    item = __builtin_amdgcn_readfirstlane(item);
+                    const int n_tiles = a.tiles_x * a.tiles_y;
+                    const bool got = item < n_tiles * a.n_chunks; // the cursor is finite: every wave sees its end
+                    const int chunk = item / n_tiles, tile = item - chunk * n_tiles;
+                    const int tj = tile / a.tiles_x, ti = tile - tj * a.tiles_x;
+                    int s0, s1;
+                    if (a.chunk_size > 0) {
+                        s0 = a.s_begin + chunk * a.chunk_size;
+                        s1 = s0 + a.chunk_size;
+                        if (s1 > a.s_end) s1 = a.s_end;
+                    } else {
+                        s0 = a.chunk_start[got ? chunk : 0];
+                        s1 = a.chunk_start[got ? chunk + 1 : 0];
+                    }
+                    const int n_new = got && cam.max_depth > 0 ? (s1 - s0) << 6 : 0; // max_depth <= 0: every sample is black (camera.h:294)
+                    if (lane == 0) {
+                        ws[WS_PREV_I0] = ws[WS_CUR_I0]; ws[WS_PREV_J0] = ws[WS_CUR_J0]; ws[WS_PREV_CHUNK] = ws[WS_CUR_CHUNK];
+                        ws[WS_PREV_VALID] = ws[WS_CUR_VALID];
+                        ws[WS_CUR_SLOT] = cur_slot ^ 1;
+                        ws[WS_CUR_I0] = ti * 8; ws[WS_CUR_J0] = tj * 8; ws[WS_CUR_CHUNK] = chunk; ws[WS_CUR_S0] = s0;
+                        ws[WS_N_UNITS] = n_new; ws[WS_CUR_VALID] = got ? 1 : 0;
+                    }
+                    units_left = got ? n_new : -1;
+                    continue;
+                }
+            }
             const bool is_box = kind == K_BOX, is_sph = kind == K_SPHERE, is_aab = kind == K_AABOX, is_med = kind == K_MEDIUM;
             const bool is_oth = kind >= K_QUAD && kind < K_IDLE; // quad, triangle, moving sphere, instance boundary
             const bool ready = kind == K_READY;
             const unsigned long long mb = lane_mask(is_box), ms = lane_mask(is_sph), ma = lane_mask(is_aab), mm = lane_mask(is_med),
                                      mo = lane_mask(is_oth), mr = lane_mask(ready);
-            if (!(mb | ms | ma | mm | mo | mr)) break;
+            if (!(mb | ms | ma | mm | mo | mr)) { // nothing in flight
+                if (units_left < 0) break;
+                continue;
+            }
             // Run ONE block per trip: shading once enough lanes wait for it, else the record kind with the largest weighted
             // number of waiting lanes (score = count * weight, block id in the low bits -> one max chain).
             const int nr = popc64(mr);
@@ -1119,6 +1170,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
 #ifdef RT_PROFILE_ACTIONS
             const unsigned long long t_a = __builtin_amdgcn_s_memtime();
             prof_idle += 64 - popc64(mb | ms | ma | mm | mo | mr);
+            if (units_left <= 0) prof_tail += 1;
             prof_ready += nr;
             prof_all += 1;
             const int n_act = action == A_BOX ? popc64(mb) : action == A_SPHERE ? popc64(ms) : action == A_AABOX ? popc64(ma)
@@ -1152,8 +1204,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                 }
             } else if (action == A_MEDIUM) {
                 if (is_med) {
-                    const int bounce_idx = cam.max_depth - depth;
-                    auto mxi = [&](int node_id) { return medium_draw<R>(k0, k1, pixel, (uint32_t)(s0 + (u >> 6)), node_id, bounce_idx); };
+                    auto mxi = [&](int node_id) { return medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce); };
                     R t;
                     if (medium_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], tv.u1.w[0], ldi(tv.u1.w[2]), tv.o, tv.d, tmin,
                                  tv.best_t, mxi, t)) {
@@ -1163,28 +1214,26 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                 }
             } else if (action == A_OTHER) {
                 if (is_oth) {
-                    const int bounce_idx = cam.max_depth - depth;
-                    auto mxi = [&](int node_id) { return medium_draw<R>(k0, k1, pixel, (uint32_t)(s0 + (u >> 6)), node_id, bounce_idx); };
+                    auto mxi = [&](int node_id) { return medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce); };
                     trav_leaf_step(mem, sc, tv, ray, tmin, mxi);
                 }
             } else {
-                bool ended = false;
                 if (ready) {
 #ifdef RT_PROFILE_ACTIONS
                     sp.last = __builtin_amdgcn_s_memtime();
 #endif
                     Rng<R> g;
-                    g.k0 = k0;
-                    g.k1 = k1;
-                    g.begin_bounce(pixel, (uint32_t)(s0 + (u >> 6)), cam.max_depth - depth);
+                    g.k0 = a.k0;
+                    g.k1 = a.k1;
+                    g.begin_bounce(pixel, (uint32_t)smp, bounce);
                     RT_STAMP(0);
                     V3<R> L;
                     bool alive = shade(mem, sc, cam, ray, tv.best_t, tv.best_off, tv.best_ctx, beta, L, g RT_SP_ARG);
 #ifdef RT_PROFILE_ACTIONS
                     sp.last = __builtin_amdgcn_s_memtime();
 #endif
-                    depth--;
-                    if (alive && depth == 0) { // depth exhausted: the recursion returns 0 here (camera.h:294-295)
+                    bounce++;
+                    if (alive && bounce == cam.max_depth) { // depth exhausted: the recursion returns 0 here (camera.h:294-295)
                         L = beta * mk<R>(R(0), R(0), R(0));
                         alive = false;
                     }
@@ -1192,13 +1241,11 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         rays++;
                         trav_begin(mem, tv, ray);
                     } else {
-                        R *const px = acc + (u & 63) * 3;
+                        R *const px = acc + pp * 3;
                         lds_add(px, L.x); lds_add(px + 1, L.y); lds_add(px + 2, L.z);
-                        tv.hdr = K_IDLE;
-                        ended = true;
+                        tv.hdr = K_IDLE; // asks for its next unit at the top of the loop
                     }
                 }
-                deal(ended);
 #ifdef RT_PROFILE_ACTIONS
                 {
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1216,15 +1263,9 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             }
 #endif
         }
-        { // every path of the item has ended: lane p stores pixel p's sums (this wave's own ds_adds, in program order)
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int i = ti * 8 + (lane & 7), j = tj * 8 + (lane >> 3);
-            if (i < cam.W && j < cam.H) {
-                size_t o = ((size_t)chunk * cam.H * cam.W + (size_t)j * cam.W + i) * 3;
-                out[o] = (float)acc[lane * 3]; out[o + 1] = (float)acc[lane * 3 + 1]; out[o + 2] = (float)acc[lane * 3 + 2];
-            }
-        }
     }
+    if (wsl(WS_PREV_VALID)) flush(wsl(WS_CUR_SLOT) ^ 1, wsl(WS_PREV_I0), wsl(WS_PREV_J0), wsl(WS_PREV_CHUNK));
+    if (wsl(WS_CUR_VALID)) flush(wsl(WS_CUR_SLOT), wsl(WS_CUR_I0), wsl(WS_CUR_J0), wsl(WS_CUR_CHUNK));
     // wave-level ray count -> one atomic per wave
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_xor(rays, off);
     if (lane == 0) atomicAdd(&counters[0], (unsigned long long)rays);
@@ -1241,6 +1282,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
         atomicAdd(&counters[33], prof_idle);
         atomicAdd(&counters[34], prof_ready);
         atomicAdd(&counters[35], prof_all);
+        atomicAdd(&counters[36], prof_tail);
     }
 #endif
 }

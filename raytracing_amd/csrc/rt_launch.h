@@ -15,21 +15,13 @@ struct RenderLaunch {
     int32_t n_cus;
 };
 
-// LDS the kernels of precision R may use for the scene (record stream + shading tables), and their workgroup size.
-//   f32: one 1024-thread workgroup per CU owns (almost) the whole 160 KiB -> 16 waves/CU, <= 128 VGPRs
-//   f64: the parity path; one 512-thread workgroup per CU (<= 256 VGPRs), 128 KiB
-// The render kernel adds accum_bytes behind the scene: per wave 64 pixels x RGB of path sums.
-template <class R> struct LaunchCfg;
-template <> struct LaunchCfg<float> {
-    static constexpr int block = 1024;
-    static constexpr int accum_bytes = block * 3 * (int)sizeof(float);
-    static constexpr int lds_bytes = 160 * 1024 - 512 - accum_bytes;
-    static constexpr int blocks_per_cu = 1;
-};
-template <> struct LaunchCfg<double> {
-    static constexpr int block = 512;
-    static constexpr int accum_bytes = block * 3 * (int)sizeof(double);
-    static constexpr int lds_bytes = 128 * 1024;
+// Workgroup size and LDS budget of the kernels of precision R: see LdsLayout (rt_scene.h).  lds_bytes is what the
+// scene (stream prefix + shading tables) may take; every launch asks for stream_off + the scene's bytes.
+template <class R> struct LaunchCfg {
+    static constexpr int block = LdsLayout<R>::block;
+    static constexpr int lds_bytes = LdsLayout<R>::scene_bytes;
+    static constexpr int lds_total = LdsLayout<R>::total_bytes;
+    static constexpr int stream_off = LdsLayout<R>::stream_off;
     static constexpr int blocks_per_cu = 1;
 };
 

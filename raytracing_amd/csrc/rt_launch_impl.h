@@ -36,12 +36,12 @@ hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const Rende
     hipError_t e;
     if (sc.lds_units == sc.n_units) {
         auto k = render_kernel<R, true, C::block>;
-        if ((e = allow_lds(k, C::lds_bytes + C::accum_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, block, lds + C::accum_bytes, stream, sc, cam, a, out, counters);
+        if ((e = allow_lds(k, C::lds_total)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, block, lds + C::stream_off, stream, sc, cam, a, out, counters);
     } else {
         auto k = render_kernel<R, false, C::block>;
-        if ((e = allow_lds(k, C::lds_bytes + C::accum_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, block, lds + C::accum_bytes, stream, sc, cam, a, out, counters);
+        if ((e = allow_lds(k, C::lds_total)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, block, lds + C::stream_off, stream, sc, cam, a, out, counters);
     }
     return hipGetLastError();
 }
@@ -62,12 +62,12 @@ hipError_t launch_trace(const SceneT<R> &sc, const rt_ray *d_rays, const double 
     hipError_t e;
     if (sc.lds_units == sc.n_units) {
         auto k = trace_kernel<R, true, C::block>;
-        if ((e = allow_lds(k, C::lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, block, lds, stream, sc, d_rays, d_xi, n, d_out, a);
+        if ((e = allow_lds(k, C::lds_total)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, block, lds + C::stream_off, stream, sc, d_rays, d_xi, n, d_out, a);
     } else {
         auto k = trace_kernel<R, false, C::block>;
-        if ((e = allow_lds(k, C::lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, block, lds, stream, sc, d_rays, d_xi, n, d_out, a);
+        if ((e = allow_lds(k, C::lds_total)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, block, lds + C::stream_off, stream, sc, d_rays, d_xi, n, d_out, a);
     }
     return hipGetLastError();
 }

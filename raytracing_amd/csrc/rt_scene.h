@@ -189,5 +189,27 @@ template <class R> struct SceneT { // device pointers; passed to kernels by valu
     int32_t lights_is_list; // lights_root is a hittable_list (hittable_list.h:52 draws the pick) vs a bare shape
 };
 
+// LDS map of a workgroup (all offsets are compile-time constants, so no register holds them):
+//   [0, cold_bytes)            the kernel's uniform arguments (scene pointers, camera, schedule): read where they are
+//                              needed instead of living in scalar registers across the traversal loops
+//   [wave_off, stream_off)     per wave: two accumulator slots (items in flight) x 64 pixels x RGB, then the wave's
+//                              item state (16 ints)
+//   [stream_off, ...)          the leading lds_units units of the record stream, then (when they fit) the shading tables
+#ifndef RT_F32_BLOCK
+#define RT_F32_BLOCK 1024
+#endif
+template <class R> struct LdsLayout {
+    static constexpr int block = sizeof(R) == 4 ? RT_F32_BLOCK : 512; // f32: 16 waves/CU, <= 128 VGPRs; f64 (parity path): 8 waves
+    static constexpr int waves = block / 64;
+    static constexpr int cold_bytes = 1024;
+    static constexpr int wave_acc = 2 * 64 * 3;                                // accumulator scalars per wave
+    static constexpr int wave_stride = wave_acc * (int)sizeof(R) + 16 * 4;     // bytes per wave
+    static constexpr int wave_off = cold_bytes;
+    static constexpr int stream_off = wave_off + waves * wave_stride;
+    static constexpr int total_bytes = sizeof(R) == 4 ? 160 * 1024 - 512 : 160 * 1024 - 512 - 16 * 1024;
+    static constexpr int scene_bytes = total_bytes - stream_off;               // stream prefix + tables
+    static_assert(stream_off % 16 == 0 && stream_off < 65536 - 64, "ds_read immediate offset");
+};
+
 } // namespace rtamd
 #endif
