@@ -1018,9 +1018,20 @@ template <class R, bool ALL_LDS, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT<R> cam_arg, RenderArgs a_arg, float *__restrict__ out,
                                                        unsigned long long *__restrict__ counters) {
     static_assert(BLOCK == LdsLayout<R>::block, "LDS layout");
-    const SceneT<R> sc = stage_scene(sc_arg);
-    const CameraT<R> &cam = cam_arg;
+    // Kernel arguments arrive as 8- and 16-dword scalar loads; left alone, the register allocator spills and reloads such a
+    // tuple WHOLE (16 v_readlane for one pointer).  Passing every field through an empty asm makes each its own value.
+    SceneT<R> sc = stage_scene(sc_arg);
+    CameraT<R> cam = cam_arg;
     const RenderArgs &a = a_arg;
+#define RT_OWN(x) asm volatile("" : "+s"(x))
+    RT_OWN(sc.cold); RT_OWN(sc.xforms); RT_OWN(sc.mats); RT_OWN(sc.texs); RT_OWN(sc.images); RT_OWN(sc.image_bytes);
+    RT_OWN(sc.perlins); RT_OWN(sc.lights); RT_OWN(sc.n_lights); RT_OWN(sc.lights_is_list);
+    RT_OWN(cam.W); RT_OWN(cam.H); RT_OWN(cam.sqrt_spp); RT_OWN(cam.max_depth); RT_OWN(cam.recip_sqrt_spp); RT_OWN(cam.defocus_angle);
+    for (int k = 0; k < 3; k++) {
+        RT_OWN(cam.center[k]); RT_OWN(cam.pixel00[k]); RT_OWN(cam.du[k]); RT_OWN(cam.dv[k]); RT_OWN(cam.ddu[k]); RT_OWN(cam.ddv[k]);
+        RT_OWN(cam.background[k]);
+    }
+#undef RT_OWN
     const Mem<R, ALL_LDS> mem{sc.stream, sc.lds_units};
     const int lane = threadIdx.x & 63;
     const R tmin = R(0.001);
@@ -1072,15 +1083,15 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
         {
             // lane state = low bits of tv.hdr: the kind of the record at the cursor, K_READY (traversal finished, waiting to
             // be shaded) or K_IDLE (no unit)
-            const int kind = tv.hdr & 15;
-            const unsigned long long midle = lane_mask(kind == K_IDLE);
+            const int kind0 = tv.hdr & 15;
+            const unsigned long long midle = lane_mask(kind0 == K_IDLE);
             if (midle && units_left >= 0) {
                 if (units_left > 0) {
                     // deal units to the idle lanes: rank among the asking lanes + the item's cursor
                     const int cur_i0 = wsl(WS_CUR_I0), cur_j0 = wsl(WS_CUR_J0), cur_s0 = wsl(WS_CUR_S0), n_item_units = wsl(WS_N_UNITS);
                     const int slot6 = wsl(WS_CUR_SLOT) << 6;
                     int next_unit = n_item_units - units_left;
-                    bool need = kind == K_IDLE;
+                    bool need = kind0 == K_IDLE;
                     unsigned long long m = midle;
                     do {
                         const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -1112,12 +1123,11 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         m = lane_mask(need);
                     } while (m && next_unit < n_item_units);
                     units_left = next_unit < n_item_units ? n_item_units - next_unit : 0;
-                    continue;
-                }
+                } else {
                 // the current item has no units left: once `prev` has drained, store it, make `cur` the new `prev`, fetch an item
                 const int cur_slot = wsl(WS_CUR_SLOT);
                 const bool prev_valid = wsl(WS_PREV_VALID) != 0;
-                if (!(prev_valid && lane_mask(kind != K_IDLE && (pp >> 6) != cur_slot))) {
+                if (!(prev_valid && lane_mask(kind0 != K_IDLE && (pp >> 6) != cur_slot))) {
                     if (prev_valid) flush(cur_slot ^ 1, wsl(WS_PREV_I0), wsl(WS_PREV_J0), wsl(WS_PREV_CHUNK));
                     int item = 0;
                     if (lane == 0) item = (int)atomicAdd(&counters[1], 1ull);
@@ -1144,18 +1154,18 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         ws[WS_N_UNITS] = n_new; ws[WS_CUR_VALID] = got ? 1 : 0;
                     }
                     units_left = got ? n_new : -1;
-                    continue;
+                }
                 }
             }
+            const int kind = tv.hdr & 15;
             const bool is_box = kind == K_BOX, is_sph = kind == K_SPHERE, is_aab = kind == K_AABOX, is_med = kind == K_MEDIUM;
             const bool is_oth = kind >= K_QUAD && kind < K_IDLE; // quad, triangle, moving sphere, instance boundary
             const bool ready = kind == K_READY;
             const unsigned long long mb = lane_mask(is_box), ms = lane_mask(is_sph), ma = lane_mask(is_aab), mm = lane_mask(is_med),
                                      mo = lane_mask(is_oth), mr = lane_mask(ready);
-            if (!(mb | ms | ma | mm | mo | mr)) { // nothing in flight
+            if (!(mb | ms | ma | mm | mo | mr)) { // nothing in flight: the next trip deals or fetches, or the wave is done
                 if (units_left < 0) break;
-                continue;
-            }
+            } else {
             // Run ONE block per trip: shading once enough lanes wait for it, else the record kind with the largest weighted
             // number of waiting lanes (score = count * weight, block id in the low bits -> one max chain).
             const int nr = popc64(mr);
@@ -1262,6 +1272,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     if (action == k) { prof_cyc[k] += dt; prof_trips[k] += 1; prof_lanes[k] += (unsigned long long)n_act; }
             }
 #endif
+            }
         }
     }
     if (wsl(WS_PREV_VALID)) flush(wsl(WS_CUR_SLOT) ^ 1, wsl(WS_PREV_I0), wsl(WS_PREV_J0), wsl(WS_PREV_CHUNK));
