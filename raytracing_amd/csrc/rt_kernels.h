@@ -203,28 +203,53 @@ template <class R, bool ALL_LDS> struct Mem {
     }
 };
 
-// Stage the stream prefix (and, when it fits, the shading tables) into LDS; returns the scene whose table pointers
-// address the LDS copies (generic pointers: flat loads resolve them).
-template <class R> RT_DEV SceneT<R> stage_scene(const SceneT<R> &sc) {
+// What the kernels see of the scene's shading tables.  TAB_LDS: the tables were staged into LDS behind the stream and are
+// addressed as offsets into rt_smem, so the lookups compile to ds_read (a pointer that may be LDS or global would make
+// every lookup a flat load).  Otherwise: offsets from the device pointer `tab`.
+template <class R, bool TAB_LDS> struct SceneV {
+    const UnitT<R> *cold;
+    const uint8_t *image_bytes;
+    const uint8_t *tab;
+    uint32_t o_xforms, o_mats, o_texs, o_images, o_perlins, o_lights;
+    int32_t n_lights, lights_is_list;
+    template <class T> RT_DEV const T *at(uint32_t off) const {
+        if constexpr (TAB_LDS) return reinterpret_cast<const T *>(rt_smem + off);
+        else return reinterpret_cast<const T *>(tab + off);
+    }
+    RT_DEV const XformT<R> &xform(int i) const { return at<XformT<R>>(o_xforms)[i]; }
+    RT_DEV const MatT<R> &mat(int i) const { return at<MatT<R>>(o_mats)[i]; }
+    RT_DEV const TexT<R> &tex(int i) const { return at<TexT<R>>(o_texs)[i]; }
+    RT_DEV const ImageT &image(int i) const { return at<ImageT>(o_images)[i]; }
+    RT_DEV const PerlinT<R> &perlin(int i) const { return at<PerlinT<R>>(o_perlins)[i]; }
+    RT_DEV const LightT<R> &light(int i) const { return at<LightT<R>>(o_lights)[i]; }
+};
+
+// Stage the stream prefix (and, for TAB_LDS, the shading tables) into LDS; returns the kernels' view of the tables.
+template <class R, bool TAB_LDS> RT_DEV SceneV<R, TAB_LDS> stage_scene(const SceneT<R> &sc) {
     UnitT<R> *l = reinterpret_cast<UnitT<R> *>(rt_smem + LdsLayout<R>::stream_off);
     for (int k = threadIdx.x; k < sc.lds_units; k += blockDim.x) l[k] = sc.stream[k];
-    SceneT<R> o = sc;
-    if (sc.tab_in_lds) {
-        unsigned char *dst = rt_smem + LdsLayout<R>::stream_off + (size_t)sc.lds_units * sizeof(UnitT<R>);
+    uint32_t base = 0;
+    if constexpr (TAB_LDS) {
+        base = (uint32_t)LdsLayout<R>::stream_off + (uint32_t)sc.lds_units * (uint32_t)sizeof(UnitT<R>);
         const rt_f4 *src = reinterpret_cast<const rt_f4 *>(sc.tab);
-        rt_f4 *d4 = reinterpret_cast<rt_f4 *>(dst);
+        rt_f4 *d4 = reinterpret_cast<rt_f4 *>(rt_smem + base);
         for (int k = threadIdx.x; k < sc.tab_bytes / 16; k += blockDim.x) d4[k] = src[k];
-        const unsigned char *base = dst; // decays to a generic pointer
-        auto rebase = [&](const void *p) { return base + (reinterpret_cast<const uint8_t *>(p) - sc.tab); };
-        o.xforms = reinterpret_cast<const XformT<R> *>(rebase(sc.xforms));
-        o.mats = reinterpret_cast<const MatT<R> *>(rebase(sc.mats));
-        o.texs = reinterpret_cast<const TexT<R> *>(rebase(sc.texs));
-        o.images = reinterpret_cast<const ImageT *>(rebase(sc.images));
-        o.perlins = reinterpret_cast<const PerlinT<R> *>(rebase(sc.perlins));
-        o.lights = reinterpret_cast<const LightT<R> *>(rebase(sc.lights));
     }
+    SceneV<R, TAB_LDS> v;
+    v.cold = sc.cold;
+    v.image_bytes = sc.image_bytes;
+    v.tab = sc.tab;
+    auto off = [&](const void *p) { return base + (uint32_t)(reinterpret_cast<const uint8_t *>(p) - sc.tab); };
+    v.o_xforms = off(sc.xforms);
+    v.o_mats = off(sc.mats);
+    v.o_texs = off(sc.texs);
+    v.o_images = off(sc.images);
+    v.o_perlins = off(sc.perlins);
+    v.o_lights = off(sc.lights);
+    v.n_lights = sc.n_lights;
+    v.lights_is_list = sc.lights_is_list;
     __syncthreads();
-    return o;
+    return v;
 }
 
 // ------------------------------------------------------------------------------------------------ intersection
@@ -391,12 +416,12 @@ template <class R> RT_DEV void xf_apply(int kind, R p0, R p1, R p2, V3<R> &o, V3
     }
 }
 
-template <class R> RT_DEV RayT<R> ray_in_ctx(const SceneT<R> &sc, const RayT<R> &world, int ctx) {
+template <class R, class SC> RT_DEV RayT<R> ray_in_ctx(const SC &sc, const RayT<R> &world, int ctx) {
     RayT<R> r = world;
     if (ctx != 0) {
-        const int depth = sc.xforms[ctx].depth;
+        const int depth = sc.xform(ctx).depth;
         for (int k = 0; k < depth; k++) {
-            const XformT<R> x = sc.xforms[sc.xforms[ctx].chain[k]];
+            const XformT<R> x = sc.xform(sc.xform(ctx).chain[k]);
             xf_apply(x.kind, x.p[0], x.p[1], x.p[2], r.o, r.d);
         }
     }
@@ -448,8 +473,8 @@ RT_DEV void trav_box_step(const Mem<R, ALL_LDS> &mem, Trav<R> &tv, R tmin) {
 }
 
 // One non-BOX record.
-template <class R, bool ALL_LDS, class MediumXi>
-RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, Trav<R> &tv, const RayT<R> &world, R tmin,
+template <class R, bool ALL_LDS, class SC, class MediumXi>
+RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SC &sc, Trav<R> &tv, const RayT<R> &world, R tmin,
                            MediumXi medium_xi) {
     const int kind = tv.hdr & 15;
     const int i = tv.i;
@@ -525,8 +550,8 @@ template <class R> RT_DEV void sphere_uv(V3<R> p, R &u, R &v) { // sphere.h:89
 }
 
 // Re-derive the full hit record of the winning primitive (same arithmetic as the reference's success path).
-template <class R, bool ALL_LDS>
-RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const RayT<R> &world, R best_t, int best_off, int best_ctx,
+template <class R, bool ALL_LDS, class SC>
+RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SC &sc, const RayT<R> &world, R best_t, int best_off, int best_ctx,
                        bool want_all) {
     Hit<R> h;
     h.t = best_t;
@@ -551,7 +576,7 @@ RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const Ra
         h.front = dot(r.d, outward) < R(0);
         h.n = h.front ? outward : -outward;
         h.mat = ldi(u1.w[0]);
-        if (want_all || sc.mats[h.mat].needs_uv) sphere_uv(outward, h.u, h.v);
+        if (want_all || sc.mat(h.mat).needs_uv) sphere_uv(outward, h.u, h.v);
         if (want_all) h.prim = ldi(sc.cold[best_off].w[3]);
     } else if (h.kind == K_AABOX) {
         // which face: the slab plane whose distance is the winning t
@@ -613,9 +638,9 @@ RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const Ra
         h.prim = ldi(u1.w[2]);
     }
     if (best_ctx != 0) { // leave object space, innermost transform first (hittable.h:62, 135-145)
-        const XformT<R> *X = sc.xforms + best_ctx;
+        const XformT<R> *X = &sc.xform(best_ctx);
         for (int k = X->depth - 1; k >= 0; k--) {
-            const XformT<R> x = sc.xforms[X->chain[k]];
+            const XformT<R> x = sc.xform(X->chain[k]);
             if (x.kind == XF_TRANSLATE) {
                 h.p = h.p + mk<R>(x.p[0], x.p[1], x.p[2]);
             } else {
@@ -655,6 +680,7 @@ template <class R> RT_DEV R perlin_noise(const PerlinT<R> &pn, V3<R> p) { // per
 template <class R> RT_DEV R perlin_turb(const PerlinT<R> &pn, V3<R> p, int depth) { // perlin.h:38
     R accum = R(0);
     R weight = R(1);
+#pragma unroll 1
     for (int i = 0; i < depth; i++) {
         accum += weight * perlin_noise(pn, p);
         weight *= R(0.5);
@@ -663,20 +689,20 @@ template <class R> RT_DEV R perlin_turb(const PerlinT<R> &pn, V3<R> p, int depth
     return m_abs(accum);
 }
 
-template <class R> RT_DEV V3<R> tex_value(const SceneT<R> &sc, int tex, R u, R v, V3<R> p) {
-    TexT<R> t = sc.texs[tex];
+template <class R, class SC> RT_DEV V3<R> tex_value(const SC &sc, int tex, R u, R v, V3<R> p) {
+    TexT<R> t = sc.tex(tex);
     for (int guard = 0; guard < 16 && t.kind == RT_TEX_CHECKER; guard++) { // texture.h:39
         int xi = int(m_floor(t.scale * p.x));
         int yi = int(m_floor(t.scale * p.y));
         int zi = int(m_floor(t.scale * p.z));
         bool even = (xi + yi + zi) % 2 == 0;
-        t = sc.texs[even ? t.a : t.b];
+        t = sc.tex(even ? t.a : t.b);
     }
     if (t.kind == RT_TEX_SOLID) return ld3(t.color); // texture.h:22
 #ifndef RT_EXP_NO_IMAGE
     if (t.kind == RT_TEX_IMAGE) {                    // texture.h:60
         if (t.a < 0) return mk<R>(R(0), R(1), R(1));
-        const ImageT im = sc.images[t.a];
+        const ImageT im = sc.image(t.a);
         if (im.height <= 0) return mk<R>(R(0), R(1), R(1));
         u = u < R(0) ? R(0) : (u > R(1) ? R(1) : u);
         v = R(1.0) - (v < R(0) ? R(0) : (v > R(1) ? R(1) : v));
@@ -696,7 +722,7 @@ template <class R> RT_DEV V3<R> tex_value(const SceneT<R> &sc, int tex, R u, R v
     if (t.kind == RT_TEX_IMAGE) return mk<R>(R(.5), R(.5), R(.5));
 #endif
     if (t.kind == RT_TEX_NOISE) { // texture.h:85
-        R s = R(1) + sin_wide(t.scale * p.z + R(10) * perlin_turb(sc.perlins[t.a], p, 7));
+        R s = R(1) + sin_wide(t.scale * p.z + R(10) * perlin_turb(sc.perlin(t.a), p, 7));
         return mk<R>(R(.5) * s, R(.5) * s, R(.5) * s);
     }
     return mk<R>(R(0), R(0), R(0));
@@ -788,21 +814,21 @@ template <class R> RT_DEV R light_pdf_one(const LightT<R> &L, V3<R> origin, V3<R
 }
 
 // `picked` = index of the light that generated `dir`, or -1 when the direction came from the BRDF sampler.
-template <class R> RT_DEV R light_pdf(const SceneT<R> &sc, V3<R> origin, V3<R> dir, int picked) {
-    if (!sc.lights_is_list) return light_pdf_one(sc.lights[0], origin, dir, picked == 0);
+template <class R, class SC> RT_DEV R light_pdf(const SC &sc, V3<R> origin, V3<R> dir, int picked) {
+    if (!sc.lights_is_list) return light_pdf_one(sc.light(0), origin, dir, picked == 0);
     R weight = R(1.0) / R(sc.n_lights); // hittable_list.h:42
     R sum = R(0);
-    for (int k = 0; k < sc.n_lights; k++) sum += weight * light_pdf_one(sc.lights[k], origin, dir, picked == k);
+    for (int k = 0; k < sc.n_lights; k++) sum += weight * light_pdf_one(sc.light(k), origin, dir, picked == k);
     return sum;
 }
 
-template <class R> RT_DEV V3<R> light_random(const SceneT<R> &sc, V3<R> origin, Rng<R> &g, int &pick) {
+template <class R, class SC> RT_DEV V3<R> light_random(const SC &sc, V3<R> origin, Rng<R> &g, int &pick) {
     pick = 0;
     if (sc.lights_is_list) { // hittable_list.h:52: random_int(0, n-1) = int(0 + n*xi)
         pick = int(R(0) + (R(sc.n_lights) - R(0)) * g.next());
         if (pick >= sc.n_lights) pick = sc.n_lights - 1; // f32 rounding guard (xi < 1 always in f64)
     }
-    const LightT<R> &L = sc.lights[pick];
+    const LightT<R> &L = sc.light(pick);
     if (L.kind == LIGHT_SPHERE) { // sphere.h:76, 98
         V3<R> direction = ld3(L.s.c) - origin;
         R distance_squared = len2(direction);
@@ -875,8 +901,8 @@ struct ShadeProf { unsigned long long last, sec[8]; };
 
 // The part of camera::ray_color (camera.h:291-326) that follows world.hit(), written iteratively: radiance
 // L += beta * (emitted | background), beta *= attenuation * scattering_pdf / pdf.  Returns false when the path ends.
-template <class R, bool ALL_LDS>
-RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const CameraT<R> &cam, RayT<R> &ray, R best_t, int best_off,
+template <class R, bool ALL_LDS, class SC>
+RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SC &sc, const CameraT<R> &cam, RayT<R> &ray, R best_t, int best_off,
                   int best_ctx, V3<R> &beta, V3<R> &L, Rng<R> &g RT_SP_PARAM) {
     // L is written only when the path ends here: every hit that scatters emits nothing (material.h:28-31), so the
     // recursion's sum of emissions has exactly one non-zero term, beta * (emitted | background).
@@ -886,7 +912,7 @@ RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SceneT<R> &sc, const CameraT
     }
     Hit<R> h = finalize(mem, sc, ray, best_t, best_off, best_ctx, false);
     RT_STAMP(1);
-    const MatT<R> m = sc.mats[h.mat];
+    const MatT<R> m = sc.mat(h.mat);
     V3<R> emitted = mk<R>(R(0), R(0), R(0));
     if (m.kind == RT_MAT_DIFFUSE_LIGHT) { // material.h:129
         if (h.front) emitted = tex_value(sc, m.tex, h.u, h.v, h.p);
@@ -1014,25 +1040,25 @@ template <class R> struct ColdT {
 enum : int { WS_CUR_I0 = 0, WS_CUR_J0, WS_CUR_CHUNK, WS_CUR_S0, WS_N_UNITS, WS_NEXT_UNIT, WS_CUR_SLOT, WS_PREV_I0, WS_PREV_J0,
              WS_PREV_CHUNK, WS_CUR_VALID, WS_PREV_VALID, WS_MORE_ITEMS };
 
-template <class R, bool ALL_LDS, int BLOCK>
+template <class R, bool ALL_LDS, bool TAB_LDS, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT<R> cam_arg, RenderArgs a_arg, float *__restrict__ out,
                                                        unsigned long long *__restrict__ counters) {
     static_assert(BLOCK == LdsLayout<R>::block, "LDS layout");
     // Kernel arguments arrive as 8- and 16-dword scalar loads; left alone, the register allocator spills and reloads such a
     // tuple WHOLE (16 v_readlane for one pointer).  Passing every field through an empty asm makes each its own value.
-    SceneT<R> sc = stage_scene(sc_arg);
+    SceneV<R, TAB_LDS> sc = stage_scene<R, TAB_LDS>(sc_arg);
     CameraT<R> cam = cam_arg;
     const RenderArgs &a = a_arg;
 #define RT_OWN(x) asm volatile("" : "+s"(x))
-    RT_OWN(sc.cold); RT_OWN(sc.xforms); RT_OWN(sc.mats); RT_OWN(sc.texs); RT_OWN(sc.images); RT_OWN(sc.image_bytes);
-    RT_OWN(sc.perlins); RT_OWN(sc.lights); RT_OWN(sc.n_lights); RT_OWN(sc.lights_is_list);
+    RT_OWN(sc.cold); RT_OWN(sc.image_bytes); RT_OWN(sc.tab); RT_OWN(sc.o_xforms); RT_OWN(sc.o_mats); RT_OWN(sc.o_texs);
+    RT_OWN(sc.o_images); RT_OWN(sc.o_perlins); RT_OWN(sc.o_lights); RT_OWN(sc.n_lights); RT_OWN(sc.lights_is_list);
     RT_OWN(cam.W); RT_OWN(cam.H); RT_OWN(cam.sqrt_spp); RT_OWN(cam.max_depth); RT_OWN(cam.recip_sqrt_spp); RT_OWN(cam.defocus_angle);
     for (int k = 0; k < 3; k++) {
         RT_OWN(cam.center[k]); RT_OWN(cam.pixel00[k]); RT_OWN(cam.du[k]); RT_OWN(cam.dv[k]); RT_OWN(cam.ddu[k]); RT_OWN(cam.ddv[k]);
         RT_OWN(cam.background[k]);
     }
 #undef RT_OWN
-    const Mem<R, ALL_LDS> mem{sc.stream, sc.lds_units};
+    const Mem<R, ALL_LDS> mem{sc_arg.stream, sc_arg.lds_units};
     const int lane = threadIdx.x & 63;
     const R tmin = R(0.001);
     // this wave's accumulators (two slots = items in flight, x 64 pixels x RGB) and item state
@@ -1304,11 +1330,11 @@ struct TraceArgs {
 };
 
 // rt_trace_batch: closest hit of each ray over [0.001, inf) (camera.h:300).
-template <class R, bool ALL_LDS, int BLOCK>
+template <class R, bool ALL_LDS, bool TAB_LDS, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) trace_kernel(SceneT<R> sc_arg, const rt_ray *__restrict__ rays, const double *__restrict__ xi,
                                                       size_t n, rt_hit *__restrict__ out, TraceArgs a) {
-    const SceneT<R> sc = stage_scene(sc_arg);
-    const Mem<R, ALL_LDS> mem{sc.stream, sc.lds_units};
+    const SceneV<R, TAB_LDS> sc = stage_scene<R, TAB_LDS>(sc_arg);
+    const Mem<R, ALL_LDS> mem{sc_arg.stream, sc_arg.lds_units};
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
         RayT<R> r;
         r.o = mk<R>(R(rays[k].orig[0]), R(rays[k].orig[1]), R(rays[k].orig[2]));

@@ -34,15 +34,16 @@ hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const Rende
     long long cap = (long long)rl.n_cus * C::blocks_per_cu;
     dim3 grid((unsigned)(want < cap ? (want < 1 ? 1 : want) : cap), 1, 1), block(C::block, 1, 1);
     hipError_t e;
-    if (sc.lds_units == sc.n_units) {
-        auto k = render_kernel<R, true, C::block>;
-        if ((e = allow_lds(k, C::lds_total)) != hipSuccess) return e;
+    auto go = [&](auto k) {
+        hipError_t e2 = allow_lds(k, C::lds_total);
+        if (e2 != hipSuccess) return e2;
         hipLaunchKernelGGL(k, grid, block, lds + C::stream_off, stream, sc, cam, a, out, counters);
-    } else {
-        auto k = render_kernel<R, false, C::block>;
-        if ((e = allow_lds(k, C::lds_total)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, block, lds + C::stream_off, stream, sc, cam, a, out, counters);
-    }
+        return hipSuccess;
+    };
+    if (sc.lds_units == sc.n_units && sc.tab_in_lds) e = go(render_kernel<R, true, true, C::block>);
+    else if (sc.lds_units == sc.n_units) e = go(render_kernel<R, true, false, C::block>);
+    else e = go(render_kernel<R, false, false, C::block>);
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 
@@ -60,15 +61,16 @@ hipError_t launch_trace(const SceneT<R> &sc, const rt_ray *d_rays, const double 
     size_t want = (n + C::block - 1) / C::block, cap = (size_t)n_cus * C::blocks_per_cu;
     dim3 grid((unsigned)(want < cap ? want : cap), 1, 1), block(C::block, 1, 1);
     hipError_t e;
-    if (sc.lds_units == sc.n_units) {
-        auto k = trace_kernel<R, true, C::block>;
-        if ((e = allow_lds(k, C::lds_total)) != hipSuccess) return e;
+    auto go = [&](auto k) {
+        hipError_t e2 = allow_lds(k, C::lds_total);
+        if (e2 != hipSuccess) return e2;
         hipLaunchKernelGGL(k, grid, block, lds + C::stream_off, stream, sc, d_rays, d_xi, n, d_out, a);
-    } else {
-        auto k = trace_kernel<R, false, C::block>;
-        if ((e = allow_lds(k, C::lds_total)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, block, lds + C::stream_off, stream, sc, d_rays, d_xi, n, d_out, a);
-    }
+        return hipSuccess;
+    };
+    if (sc.lds_units == sc.n_units && sc.tab_in_lds) e = go(trace_kernel<R, true, true, C::block>);
+    else if (sc.lds_units == sc.n_units) e = go(trace_kernel<R, true, false, C::block>);
+    else e = go(trace_kernel<R, false, false, C::block>);
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 
