@@ -1037,8 +1037,8 @@ template <class R> struct ColdT {
     RenderArgs a;
 };
 // per-wave item state (16 ints behind the wave's accumulators)
-enum : int { WS_CUR_I0 = 0, WS_CUR_J0, WS_CUR_CHUNK, WS_CUR_S0, WS_N_UNITS, WS_NEXT_UNIT, WS_CUR_SLOT, WS_PREV_I0, WS_PREV_J0,
-             WS_PREV_CHUNK, WS_CUR_VALID, WS_PREV_VALID, WS_MORE_ITEMS };
+// slot k: ws[4k .. 4k+3] = tile origin i0, j0, chunk, valid; then the dealing item's slot, first sample and unit count
+enum : int { WS_SLOT_I0 = 0, WS_SLOT_J0 = 1, WS_SLOT_CHUNK = 2, WS_SLOT_VALID = 3, WS_CUR_SLOT = 24, WS_CUR_S0 = 25, WS_N_UNITS = 26 };
 
 template <class R, bool ALL_LDS, bool TAB_LDS, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT<R> cam_arg, RenderArgs a_arg, float *__restrict__ out,
@@ -1078,8 +1078,10 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     // dealing while the old item's last paths finish (two items in flight: `cur` deals, `prev` drains).  The RNG is keyed
     // by (pixel, sample), so the image does not depend on who traces what; a finished path is added to its item's
     // 64-pixel accumulator in LDS (ds_add: the order of the adds is this wave's own deterministic schedule).
-    for (int k = 0; k < 6; k++) acc[lane + 64 * k] = R(0);
-    if (lane < 16) ws[lane] = 0;
+    constexpr int NS = LdsLayout<R>::item_slots;
+    static_assert(NS >= 2 && NS <= 4, "slot id: 2 bits of pp; item state: 32 ints");
+    for (int k = 0; k < 3 * NS; k++) acc[lane + 64 * k] = R(0);
+    if (lane < 32) ws[lane] = 0;
     RayT<R> ray;
     V3<R> beta;
     Trav<R> tv;
@@ -1114,8 +1116,9 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             if (midle && units_left >= 0) {
                 if (units_left > 0) {
                     // deal units to the idle lanes: rank among the asking lanes + the item's cursor
-                    const int cur_i0 = wsl(WS_CUR_I0), cur_j0 = wsl(WS_CUR_J0), cur_s0 = wsl(WS_CUR_S0), n_item_units = wsl(WS_N_UNITS);
-                    const int slot6 = wsl(WS_CUR_SLOT) << 6;
+                    const int cur_slot = wsl(WS_CUR_SLOT), cur_s0 = wsl(WS_CUR_S0), n_item_units = wsl(WS_N_UNITS);
+                    const int cur_i0 = wsl(4 * cur_slot + WS_SLOT_I0), cur_j0 = wsl(4 * cur_slot + WS_SLOT_J0);
+                    const int slot6 = cur_slot << 6;
                     int next_unit = n_item_units - units_left;
                     bool need = kind0 == K_IDLE;
                     unsigned long long m = midle;
@@ -1150,11 +1153,12 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     } while (m && next_unit < n_item_units);
                     units_left = next_unit < n_item_units ? n_item_units - next_unit : 0;
                 } else {
-                // the current item has no units left: once `prev` has drained, store it, make `cur` the new `prev`, fetch an item
-                const int cur_slot = wsl(WS_CUR_SLOT);
-                const bool prev_valid = wsl(WS_PREV_VALID) != 0;
-                if (!(prev_valid && lane_mask(kind0 != K_IDLE && (pp >> 6) != cur_slot))) {
-                    if (prev_valid) flush(cur_slot ^ 1, wsl(WS_PREV_I0), wsl(WS_PREV_J0), wsl(WS_PREV_CHUNK));
+                // the current item has no units left: take the next accumulator slot (once the item that used it NS items
+                // ago has drained: store it first) and fetch an item into it
+                const int t = wsl(WS_CUR_SLOT) + 1 == NS ? 0 : wsl(WS_CUR_SLOT) + 1;
+                const bool t_valid = wsl(4 * t + WS_SLOT_VALID) != 0;
+                if (!(t_valid && lane_mask(kind0 != K_IDLE && (pp >> 6) == t))) {
+                    if (t_valid) flush(t, wsl(4 * t + WS_SLOT_I0), wsl(4 * t + WS_SLOT_J0), wsl(4 * t + WS_SLOT_CHUNK));
                     int item = 0;
                     if (lane == 0) item = (int)atomicAdd(&counters[1], 1ull);
                     item = __builtin_amdgcn_readfirstlane(item);
@@ -1173,11 +1177,9 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     }
                     const int n_new = got && cam.max_depth > 0 ? (s1 - s0) << 6 : 0; // max_depth <= 0: every sample is black (camera.h:294)
                     if (lane == 0) {
-                        ws[WS_PREV_I0] = ws[WS_CUR_I0]; ws[WS_PREV_J0] = ws[WS_CUR_J0]; ws[WS_PREV_CHUNK] = ws[WS_CUR_CHUNK];
-                        ws[WS_PREV_VALID] = ws[WS_CUR_VALID];
-                        ws[WS_CUR_SLOT] = cur_slot ^ 1;
-                        ws[WS_CUR_I0] = ti * 8; ws[WS_CUR_J0] = tj * 8; ws[WS_CUR_CHUNK] = chunk; ws[WS_CUR_S0] = s0;
-                        ws[WS_N_UNITS] = n_new; ws[WS_CUR_VALID] = got ? 1 : 0;
+                        ws[4 * t + WS_SLOT_I0] = ti * 8; ws[4 * t + WS_SLOT_J0] = tj * 8; ws[4 * t + WS_SLOT_CHUNK] = chunk;
+                        ws[4 * t + WS_SLOT_VALID] = got ? 1 : 0;
+                        ws[WS_CUR_SLOT] = t; ws[WS_CUR_S0] = s0; ws[WS_N_UNITS] = n_new;
                     }
                     units_left = got ? n_new : -1;
                 }
@@ -1301,8 +1303,8 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             }
         }
     }
-    if (wsl(WS_PREV_VALID)) flush(wsl(WS_CUR_SLOT) ^ 1, wsl(WS_PREV_I0), wsl(WS_PREV_J0), wsl(WS_PREV_CHUNK));
-    if (wsl(WS_CUR_VALID)) flush(wsl(WS_CUR_SLOT), wsl(WS_CUR_I0), wsl(WS_CUR_J0), wsl(WS_CUR_CHUNK));
+    for (int k = 0; k < NS; k++)
+        if (wsl(4 * k + WS_SLOT_VALID)) flush(k, wsl(4 * k + WS_SLOT_I0), wsl(4 * k + WS_SLOT_J0), wsl(4 * k + WS_SLOT_CHUNK));
     // wave-level ray count -> one atomic per wave
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_xor(rays, off);
     if (lane == 0) atomicAdd(&counters[0], (unsigned long long)rays);
