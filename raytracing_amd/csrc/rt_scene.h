@@ -190,9 +190,7 @@ template <class R> struct SceneT { // device pointers; passed to kernels by valu
 };
 
 // LDS map of a workgroup (all offsets are compile-time constants, so no register holds them):
-//   [0, cold_bytes)            the kernel's uniform arguments (scene pointers, camera, schedule): read where they are
-//                              needed instead of living in scalar registers across the traversal loops
-//   [wave_off, stream_off)     per wave: item_slots accumulator slots (items in flight) x 64 pixels x RGB, then the
+//   [0, stream_off)            per wave: item_slots accumulator slots (items in flight) x 64 pixels x RGB, then the
 //                              wave's item state (32 ints)
 //   [stream_off, ...)          the leading lds_units units of the record stream, then (when they fit) the shading tables
 #ifndef RT_ITEM_SLOTS
@@ -204,11 +202,10 @@ template <class R> struct SceneT { // device pointers; passed to kernels by valu
 template <class R> struct LdsLayout {
     static constexpr int block = sizeof(R) == 4 ? RT_F32_BLOCK : 512; // f32: 16 waves/CU, <= 128 VGPRs; f64 (parity path): 8 waves
     static constexpr int waves = block / 64;
-    static constexpr int cold_bytes = 1024;
     static constexpr int item_slots = RT_ITEM_SLOTS;                           // items in flight per wave
     static constexpr int wave_acc = item_slots * 64 * 3;                       // accumulator scalars per wave
     static constexpr int wave_stride = wave_acc * (int)sizeof(R) + 32 * 4;     // bytes per wave (+ 32 ints of item state)
-    static constexpr int wave_off = cold_bytes;
+    static constexpr int wave_off = 0;
     static constexpr int stream_off = wave_off + waves * wave_stride;
     static constexpr int total_bytes = sizeof(R) == 4 ? 160 * 1024 - 512 : 160 * 1024 - 512 - 16 * 1024;
     static constexpr int scene_bytes = total_bytes - stream_off;               // stream prefix + tables
