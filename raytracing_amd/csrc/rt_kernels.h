@@ -1007,10 +1007,10 @@ enum : int { RT_MAX_SCHED_CHUNKS = 24 };
 #define RT_SHADE_T 40
 #endif
 #ifndef RT_BOX_REPEAT
-#define RT_BOX_REPEAT 12
+#define RT_BOX_REPEAT 24
 #endif
 #ifndef RT_BOX_REPEAT_MIN
-#define RT_BOX_REPEAT_MIN 6
+#define RT_BOX_REPEAT_MIN 8
 #endif
 struct RenderArgs {
     uint32_t k0, k1;
