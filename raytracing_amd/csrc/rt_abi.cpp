@@ -363,6 +363,7 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
     rl.n_chunks = n_chunks;
     rl.n_cus = ctx->n_cus;
     HIP_TRY(ctx, hipMemsetAsync(ctx->counter, 0, 40 * sizeof(unsigned long long), stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counter + 37, 0xff, sizeof(unsigned long long), stream)); // [37]: a minimum (diagnostic builds)
     if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     if (params->precision == RT_PREC_F64)
         HIP_TRY(ctx, launch_render<double>(scene->f64.sc, convert_camera<double>(*cam), rl, target, ctx->counter, stream));
@@ -394,6 +395,14 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
                 std::fprintf(stderr, "[rt_amd profile]   shade/%-30s %.1f%% of wave time\n", nm[k], 100.0 * (double)c[24 + k] / (double)(c[3] ? c[3] : 1));
             std::fprintf(stderr, "[rt_amd profile] per trip: %.1f lanes idle (item tail), %.1f lanes waiting for shading, of 64; %.1f%% of trips after the item's last unit was dealt\n",
                          (double)c[33] / (double)(c[35] ? c[35] : 1), (double)c[34] / (double)(c[35] ? c[35] : 1), 100.0 * (double)c[36] / (double)(c[35] ? c[35] : 1));
+        }
+        if (std::getenv("RT_AMD_PROFILE_TAIL")) { // builds with -DRT_PROFILE_TAIL: wave end times
+            unsigned long long c[40];
+            HIP_TRY(ctx, hipMemcpy(c, ctx->counter, sizeof(c), hipMemcpyDeviceToHost));
+            const double span = (double)(c[38] - c[37]), n_waves = (double)ctx->n_cus * 16.0;
+            std::fprintf(stderr, "[rt_amd profile] waves busy on average %.1f%% of the kernel's span (first start to last end); wave run time min %.1f%% max %.1f%% of the span\n",
+                         span > 0 ? 100.0 * (double)c[39] / n_waves / span : 0.0, span > 0 ? 100.0 * (double)(~c[35]) / span : 0.0,
+                         span > 0 ? 100.0 * (double)c[36] / span : 0.0);
         }
         stats->samples = (uint64_t)n_px * (uint64_t)n_samples;
         stats->rays = rays;

@@ -1057,6 +1057,9 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     R *const acc = reinterpret_cast<R *>(rt_smem + LdsLayout<R>::wave_off + (threadIdx.x >> 6) * LdsLayout<R>::wave_stride);
     int *const ws = reinterpret_cast<int *>(acc + LdsLayout<R>::wave_acc);
     unsigned rays = 0;
+#ifdef RT_PROFILE_TAIL
+    const unsigned long long t_tail0 = __builtin_amdgcn_s_memrealtime(); // device-wide constant-rate clock
+#endif
 #ifdef RT_PROFILE_ACTIONS
     unsigned long long prof_cyc[A_COUNT] = {}, prof_trips[A_COUNT] = {}, prof_lanes[A_COUNT] = {};
     const unsigned long long t_wave0 = __builtin_amdgcn_s_memtime();
@@ -1300,6 +1303,16 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     // wave-level ray count -> one atomic per wave
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_xor(rays, off);
     if (lane == 0) atomicAdd(&counters[0], (unsigned long long)rays);
+#ifdef RT_PROFILE_TAIL
+    if (lane == 0) { // diagnostic build: how long did this wave have work, relative to the kernel's span?
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        atomicMin(&counters[37], t_tail0);
+        atomicMax(&counters[38], t1);
+        atomicAdd(&counters[39], t1 - t_tail0);
+        atomicMax(&counters[36], t1 - t_tail0);
+        atomicMax(&counters[35], ~(t1 - t_tail0)); // maximum of the complement = minimum duration (the counter starts at zero)
+    }
+#endif
 #ifdef RT_PROFILE_ACTIONS
     if (lane == 0) {
         for (int k = 0; k < A_COUNT; k++) {

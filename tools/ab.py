@@ -20,5 +20,5 @@ for spec in sys.argv[1:]:
     for kv in parts[1:]:
         k, v = kv.split("=")
         env[k] = v
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=200)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=90)
     print(spec, "->", r.stdout.strip() or r.stderr.strip()[-300:], flush=True)
