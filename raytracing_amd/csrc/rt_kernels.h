@@ -84,7 +84,17 @@ template <class R> RT_DEV V3<R> operator-(V3<R> a, V3<R> b) { return mk<R>(a.x -
 template <class R> RT_DEV V3<R> operator-(V3<R> a) { return mk<R>(-a.x, -a.y, -a.z); }
 template <class R> RT_DEV V3<R> operator*(V3<R> a, V3<R> b) { return mk<R>(a.x * b.x, a.y * b.y, a.z * b.z); }
 template <class R> RT_DEV V3<R> scale(R t, V3<R> v) { return mk<R>(t * v.x, t * v.y, t * v.z); }           // vec3.h:78
-template <class R> RT_DEV V3<R> divide(V3<R> v, R t) { return scale<R>(R(1) / t, v); }                      // vec3.h:86
+// Division: the double path divides (reference arithmetic); the float path multiplies by v_rcp_f32 (1 ulp) -- hipcc's float
+// division is a 5-6 instruction sequence (frexp / rcp / ldexp range scaling) even without correct rounding.
+template <class R> RT_DEV R m_rcp(R x) {
+    if constexpr (sizeof(R) == 4) return __builtin_amdgcn_rcpf(x);
+    else return R(1) / x;
+}
+template <class R> RT_DEV R m_div(R a, R b) {
+    if constexpr (sizeof(R) == 4) return a * __builtin_amdgcn_rcpf(b);
+    else return a / b;
+}
+template <class R> RT_DEV V3<R> divide(V3<R> v, R t) { return scale<R>(m_rcp(t), v); }                      // vec3.h:86
 template <class R> RT_DEV R dot(V3<R> u, V3<R> v) { return u.x * v.x + u.y * v.y + u.z * v.z; }             // vec3.h:90
 template <class R> RT_DEV V3<R> cross(V3<R> u, V3<R> v) {                                                   // vec3.h:96
     return mk<R>(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x);
@@ -312,13 +322,13 @@ template <class R> RT_DEV bool sphere_t(V3<R> cc, R radius, V3<R> ro, V3<R> rd, 
         // Same quadratic, conditioned for float: h*h - a*c cancels catastrophically when |oc| >> radius (first_scene's
         // r=1 light 1000 units away, the r=1000 ground, final_scene's r=5000 fog).  disc = a*(r^2 - |oc - (h/a)d|^2) and
         // the roots c/q, q/a with q = h + sign(h)*sqrt(disc) are algebraically identical and lose no digits.
-        R inva = R(1) / a;
+        R inva = m_rcp(a);
         V3<R> perp = oc - scale<R>(h * inva, rd);
         R disc = a * (radius * radius - len2(perp));
         if (disc < R(0)) return false;
         R sq = m_sqrt(disc);
         R q = h + (h < R(0) ? -sq : sq);
-        R ta = c / q, tb = q * inva;
+        R ta = m_div(c, q), tb = q * inva;
         R t0 = m_min(ta, tb), t1 = m_max(ta, tb);
         if (q == R(0)) { t0 = R(0); t1 = R(0); }
         R root = t0;
@@ -350,7 +360,7 @@ RT_DEV bool quad_t(V3<R> n, R D, V3<R> Q, V3<R> qu, V3<R> qv, V3<R> w, V3<R> ro,
                    R &beta) { // quad.h:32
     R denom = dot(n, rd);
     if (m_abs(denom) < R(1e-8)) return false;
-    R t = (D - dot(n, ro)) / denom;
+    R t = m_div(D - dot(n, ro), denom);
     if (!(tmin <= t && t <= tmax)) return false; // interval::contains
     V3<R> ph = (ro + scale<R>(t, rd)) - Q;
     alpha = dot(w, cross(ph, qv));
@@ -402,7 +412,7 @@ RT_DEV bool medium_t(V3<R> cc, R radius, R neg_inv_density, int node_id, V3<R> r
     R distance_inside_boundary = (t2 - t1) * ray_length;
     R hit_distance = neg_inv_density * m_log(xi_fn(node_id));
     if (hit_distance > distance_inside_boundary) return false;
-    t_out = t1 + hit_distance / ray_length;
+    t_out = t1 + m_div(hit_distance, ray_length);
     return true;
 }
 
@@ -428,7 +438,7 @@ template <class R, class SC> RT_DEV RayT<R> ray_in_ctx(const SC &sc, const RayT<
     return r;
 }
 
-template <class R> RT_DEV V3<R> inv_dir(V3<R> d) { return mk<R>(R(1.0) / d.x, R(1.0) / d.y, R(1.0) / d.z); } // aabb.h:42
+template <class R> RT_DEV V3<R> inv_dir(V3<R> d) { return mk<R>(m_rcp(d.x), m_rcp(d.y), m_rcp(d.z)); } // aabb.h:42
 
 // Per-ray traversal state of world.hit(r, interval(tmin, inf), rec): a cursor into the threaded stream (pre-order ==
 // the reference's recursion order), the ray in the current transform context and the closest hit so far.
@@ -545,8 +555,8 @@ template <class R> RT_DEV void sphere_uv(V3<R> p, R &u, R &v) { // sphere.h:89
     if constexpr (sizeof(R) == 4) ny = m_max(R(-1), m_min(R(1), ny)); // (p-c)/r can exceed 1 by an ulp in float
     R theta = m_acos(ny);
     R phi = m_atan2(-p.z, p.x) + Const<R>::pi;
-    u = phi / (R(2) * Const<R>::pi);
-    v = theta / Const<R>::pi;
+    u = m_div(phi, R(2) * Const<R>::pi);
+    v = m_div(theta, Const<R>::pi);
 }
 
 // Re-derive the full hit record of the winning primitive (same arithmetic as the reference's success path).
@@ -783,7 +793,7 @@ template <class R> RT_DEV R light_pdf_one(const LightT<R> &L, V3<R> origin, V3<R
         R t;
         if (!skip_test && !sphere_t(L.s, r, R(0.001), Const<R>::inf, t)) return R(0);
         R dist_squared = len2(ld3(L.s.c) - origin);
-        R x = L.s.radius * L.s.radius / dist_squared;
+        R x = m_div(L.s.radius * L.s.radius, dist_squared);
         if constexpr (sizeof(R) == 4) {
             // an origin ON the sphere (the floor point a sphere rests on) lands a few ulp inside it in float: x = 1 + eps
             // would give sqrt(<0).  Genuinely interior origins (x well above 1) keep the reference's NaN (sphere.h:70).
@@ -791,9 +801,9 @@ template <class R> RT_DEV R light_pdf_one(const LightT<R> &L, V3<R> origin, V3<R
         }
         R cos_theta_max = m_sqrt(R(1) - x);
         R one_minus_cos = R(1) - cos_theta_max;
-        if constexpr (sizeof(R) == 4) one_minus_cos = x / (R(1) + cos_theta_max); // same value, no cancellation in float
+        if constexpr (sizeof(R) == 4) one_minus_cos = m_div(x, R(1) + cos_theta_max); // same value, no cancellation in float
         R solid_angle = R(2) * Const<R>::pi * one_minus_cos;
-        return R(1) / solid_angle;
+        return m_rcp(solid_angle);
     }
     if (L.kind == LIGHT_QUAD) { // quad.h:75
         R t, al, be;
@@ -801,14 +811,14 @@ template <class R> RT_DEV R light_pdf_one(const LightT<R> &L, V3<R> origin, V3<R
             V3<R> n = ld3(L.q.n);
             R denom = dot(n, dir);
             if (m_abs(denom) < R(1e-8)) return R(0);
-            t = (L.q.D - dot(n, origin)) / denom;
+            t = m_div(L.q.D - dot(n, origin), denom);
             if (!(t >= R(0.001))) return R(0);
         } else {
             if (!quad_t(L.q, r, R(0.001), Const<R>::inf, t, al, be)) return R(0);
         }
         R distance_squared = t * t * len2(dir);
-        R cosine = m_abs(dot(dir, ld3(L.q.n)) / len(dir)); // |.| makes the face flip of rec.normal irrelevant
-        return distance_squared / (cosine * L.q.area);
+        R cosine = m_abs(m_div(dot(dir, ld3(L.q.n)), len(dir))); // |.| makes the face flip of rec.normal irrelevant
+        return m_div(distance_squared, cosine * L.q.area);
     }
     return R(0); // hittable.h:35
 }
@@ -816,7 +826,7 @@ template <class R> RT_DEV R light_pdf_one(const LightT<R> &L, V3<R> origin, V3<R
 // `picked` = index of the light that generated `dir`, or -1 when the direction came from the BRDF sampler.
 template <class R, class SC> RT_DEV R light_pdf(const SC &sc, V3<R> origin, V3<R> dir, int picked) {
     if (!sc.lights_is_list) return light_pdf_one(sc.light(0), origin, dir, picked == 0);
-    R weight = R(1.0) / R(sc.n_lights); // hittable_list.h:42
+    R weight = m_rcp(R(sc.n_lights)); // hittable_list.h:42
     R sum = R(0);
     for (int k = 0; k < sc.n_lights; k++) sum += weight * light_pdf_one(sc.light(k), origin, dir, picked == k);
     return sum;
@@ -835,7 +845,7 @@ template <class R, class SC> RT_DEV V3<R> light_random(const SC &sc, V3<R> origi
         Onb<R> uvw(direction);
         R r1 = g.next();
         R r2 = g.next();
-        R x = L.s.radius * L.s.radius / distance_squared;
+        R x = m_div(L.s.radius * L.s.radius, distance_squared);
         if constexpr (sizeof(R) == 4) {
             if (x > R(1) && x < R(1.0001)) x = R(1); // see light_pdf_one
         }
@@ -845,7 +855,7 @@ template <class R, class SC> RT_DEV V3<R> light_random(const SC &sc, V3<R> origi
         sincos_rev(r1, sp, cp); // phi = 2*pi*r1
         R s = m_sqrt(R(1) - z * z);
         if constexpr (sizeof(R) == 4) { // 1-z = r2*x/(1+cm) exactly; sqrt(1-z^2) = sqrt((1-z)(1+z)) keeps the small cone angle
-            R omz = r2 * x / (R(1) + cm);
+            R omz = m_div(r2 * x, R(1) + cm);
             z = R(1) - omz;
             s = m_sqrt(omz * (R(1) + z));
         }
@@ -931,14 +941,14 @@ RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SC &sc, const CameraT<R> &ca
     }
     RT_STAMP(3);
     if (m.kind == RT_MAT_DIELECTRIC) { // material.h:88
-        R ri = h.front ? (R(1.0) / m.ior) : m.ior;
+        R ri = h.front ? m_rcp(m.ior) : m.ior;
         V3<R> ud = unit(ray.d);
         R cos_theta = m_min(dot(-ud, h.n), R(1.0));
         R sin_theta = m_sqrt(R(1.0) - cos_theta * cos_theta);
         bool cannot_refract = ri * sin_theta > R(1.0);
         bool do_reflect = cannot_refract;
         if (!do_reflect) {
-            R r0 = (R(1) - ri) / (R(1) + ri);
+            R r0 = m_div(R(1) - ri, R(1) + ri);
             r0 = r0 * r0;
             R refl = r0 + (R(1) - r0) * m_pow5(R(1) - cos_theta);
             do_reflect = refl > g.next();
@@ -964,15 +974,15 @@ RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SC &sc, const CameraT<R> &ca
     R v1, spdf;
     if (lambert) {
         R cosine_theta = dot(unit(dir), unit(h.n)); // cosine_pdf::value pdf.h:35 (onb re-normalises w)
-        v1 = m_max(R(0), cosine_theta / Const<R>::pi);
+        v1 = m_max(R(0), m_div(cosine_theta, Const<R>::pi));
         R cos_theta = dot(h.n, unit(dir)); // lambertian::scattering_pdf material.h:51
-        spdf = cos_theta < R(0) ? R(0) : cos_theta / Const<R>::pi;
+        spdf = cos_theta < R(0) ? R(0) : m_div(cos_theta, Const<R>::pi);
     } else {
         v1 = R(1) / (R(4) * Const<R>::pi);   // pdf.h:21
         spdf = R(1) / (R(4) * Const<R>::pi); // material.h:153
     }
     R pdf_value = R(0.5) * v0 + R(0.5) * v1;
-    R wgt = spdf / pdf_value;
+    R wgt = m_div(spdf, pdf_value);
     beta = beta * scale<R>(wgt, atten);
     ray.o = h.p;
     ray.d = dir;
