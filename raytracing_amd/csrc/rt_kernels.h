@@ -24,7 +24,7 @@ namespace rtamd {
 #define RT_DEV __device__ __forceinline__
 
 // ------------------------------------------------------------------------------------------------ scalar helpers
-RT_DEV float m_sqrt(float x) { return sqrtf(x); }
+RT_DEV float m_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); } // v_sqrt_f32 (1 ulp); sqrtf() adds denormal range scaling: 6 instructions
 RT_DEV double m_sqrt(double x) { return sqrt(x); }
 RT_DEV float m_sin(float x) { return sinf(x); }
 RT_DEV double m_sin(double x) { return sin(x); }
@@ -101,7 +101,10 @@ template <class R> RT_DEV V3<R> cross(V3<R> u, V3<R> v) {                       
 }
 template <class R> RT_DEV R len2(V3<R> v) { return v.x * v.x + v.y * v.y + v.z * v.z; }                     // vec3.h:41
 template <class R> RT_DEV R len(V3<R> v) { return m_sqrt(len2(v)); }
-template <class R> RT_DEV V3<R> unit(V3<R> v) { return divide<R>(v, len(v)); }                              // vec3.h:102
+template <class R> RT_DEV V3<R> unit(V3<R> v) { // vec3.h:102
+    if constexpr (sizeof(R) == 4) return scale<R>(__builtin_amdgcn_rsqf(len2(v)), v);
+    else return divide<R>(v, len(v));
+}
 template <class R> RT_DEV V3<R> reflect(V3<R> v, V3<R> n) { return v - scale<R>(R(2) * dot(v, n), n); }     // vec3.h:131
 template <class R> RT_DEV V3<R> refract(V3<R> uv, V3<R> n, R etai_over_etat) {                              // vec3.h:135
     R cos_theta = m_min(dot(-uv, n), R(1));
@@ -769,7 +772,7 @@ template <> RT_DEV V3<float> random_unit_vector<float>(Rng<float> &g) {
         float x = g.next(-1.f, 1.f);
         V3<float> p = mk<float>(x, y, z);
         float lensq = len2(p);
-        if (1e-30f < lensq && lensq <= 1.0f) return divide<float>(p, m_sqrt(lensq)); // 1e-160 underflows float
+        if (1e-30f < lensq && lensq <= 1.0f) return scale<float>(__builtin_amdgcn_rsqf(lensq), p); // 1e-160 underflows float
     }
 }
 
