@@ -269,11 +269,13 @@ template <class R, bool TAB_LDS> RT_DEV SceneV<R, TAB_LDS> stage_scene(const Sce
 // aabb::hit (aabb.h:36) over the interval (tmin, tmax).  The double path keeps the reference's statement order; the
 // float path computes the same slab distances and folds them with min/max.
 template <class R>
-RT_DEV bool box_hit(const UnitT<R> &u0, const UnitT<R> &u1, V3<R> o, V3<R> inv, R tmin, R tmax) {
+RT_DEV bool box_hit(const UnitT<R> &u0, const UnitT<R> &u1, V3<R> o, V3<R> inv, V3<R> noi, R tmin, R tmax) {
     const R bx0 = u0.w[0], bx1 = u0.w[1], by0 = u0.w[2], by1 = u0.w[3], bz0 = u1.w[0], bz1 = u1.w[1];
     if constexpr (sizeof(R) == 4) {
-        // (min, max) pairs sit in adjacent registers: v_pk_add_f32 / v_pk_mul_f32 do both slab planes of an axis at once
-        const rt_f2 tx = (rt_f2{bx0, bx1} - o.x) * inv.x, ty = (rt_f2{by0, by1} - o.y) * inv.y, tz = (rt_f2{bz0, bz1} - o.z) * inv.z;
+        // (min, max) pairs sit in adjacent registers: one v_pk_fma_f32 does both slab planes of an axis, (b - o) * inv
+        // as b * inv + (-o * inv).  A direction component that is exactly zero makes the axis' distances NaN instead of
+        // +-inf; min / max drop NaNs, so that axis then always passes: conservative for a bounding box (leaves are exact).
+        const rt_f2 tx = rt_f2{bx0, bx1} * inv.x + noi.x, ty = rt_f2{by0, by1} * inv.y + noi.y, tz = rt_f2{bz0, bz1} * inv.z + noi.z;
         R tn = m_max(m_max(m_min(tx.x, tx.y), m_min(ty.x, ty.y)), m_max(m_min(tz.x, tz.y), tmin));
         R tf = m_min(m_min(m_max(tx.x, tx.y), m_max(ty.x, ty.y)), m_min(m_max(tz.x, tz.y), tmax));
         return tf > tn;
@@ -447,6 +449,7 @@ template <class R> RT_DEV V3<R> inv_dir(V3<R> d) { return mk<R>(m_rcp(d.x), m_rc
 // the reference's recursion order), the ray in the current transform context and the closest hit so far.
 template <class R> struct Trav {
     V3<R> o, d, inv; // ray in the space of context `ctx`
+    V3<R> noi;       // float path: -o * inv, so that a slab distance is one fma (b * inv + noi)
     R best_t;
     int best_off; // stream offset of the winning record, -1 = miss
     int best_ctx;
@@ -471,6 +474,7 @@ RT_DEV void trav_begin(const Mem<R, ALL_LDS> &mem, Trav<R> &tv, const RayT<R> &w
     tv.o = world.o;
     tv.d = world.d;
     tv.inv = inv_dir(world.d);
+    if constexpr (sizeof(R) == 4) tv.noi = -(tv.o * tv.inv);
     tv.best_t = Const<R>::inf;
     tv.best_off = -1;
     tv.best_ctx = 0;
@@ -481,7 +485,7 @@ RT_DEV void trav_begin(const Mem<R, ALL_LDS> &mem, Trav<R> &tv, const RayT<R> &w
 // One BOX record: descend (next record) or take the skip link.
 template <class R, bool ALL_LDS>
 RT_DEV void trav_box_step(const Mem<R, ALL_LDS> &mem, Trav<R> &tv, R tmin) {
-    const bool hit = box_hit(tv.u0, tv.u1, tv.o, tv.inv, tmin, tv.best_t);
+    const bool hit = box_hit(tv.u0, tv.u1, tv.o, tv.inv, tv.noi, tmin, tv.best_t);
     trav_goto(mem, tv, hit ? tv.i + 2 : ldi(tv.u1.w[2]));
 }
 
@@ -533,6 +537,7 @@ RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SC &sc, Trav<R> &tv
     } else if (kind == K_XF_ENTER) {
         xf_apply(ldi(tv.u1.w[0]), tv.u0.w[0], tv.u0.w[1], tv.u0.w[2], tv.o, tv.d);
         tv.inv = inv_dir(tv.d);
+        if constexpr (sizeof(R) == 4) tv.noi = -(tv.o * tv.inv);
         tv.ctx = ldi(tv.u1.w[1]);
     } else if (kind == K_XF_EXIT) {
         tv.ctx = ldi(tv.u1.w[1]);
@@ -540,6 +545,7 @@ RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SC &sc, Trav<R> &tv
         tv.o = r.o;
         tv.d = r.d;
         tv.inv = inv_dir(r.d);
+        if constexpr (sizeof(R) == 4) tv.noi = -(tv.o * tv.inv);
     }
     trav_goto(mem, tv, next);
 }
