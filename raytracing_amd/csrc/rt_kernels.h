@@ -129,8 +129,10 @@ RT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
 #endif
 #pragma unroll
     for (int r = 0; r < RT_PHILOX_ROUNDS; r++) {
-        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        // one v_mad_u64_u32 per product (same issue cost as v_mul_lo_u32 or v_mul_hi_u32 alone)
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
+        uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
         uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u;
