@@ -1033,6 +1033,15 @@ enum : int { RT_MAX_SCHED_CHUNKS = 24 };
 #ifndef RT_BOX_REPEAT_MIN
 #define RT_BOX_REPEAT_MIN 8
 #endif
+#ifndef RT_LEAF_REPEAT // SPHERE / AABOX steps per trip while at least RT_LEAF_REPEAT_MIN lanes of the block stay at that kind
+#define RT_LEAF_REPEAT 2
+#endif
+#ifndef RT_LEAF_REPEAT_MIN
+#define RT_LEAF_REPEAT_MIN 4
+#endif
+#ifndef RT_OTHER_REPEAT // the same for the block of the rarer kinds (a box() is six quads in a row, a mesh leaf two triangles)
+#define RT_OTHER_REPEAT 1
+#endif
 struct RenderArgs {
     uint32_t k0, k1;
     int32_t s_begin, s_end;
@@ -1243,18 +1252,33 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     if (popc64(lane_mask(at_box)) < RT_BOX_REPEAT_MIN) break;
                 }
             } else if (action == A_SPHERE) {
-                if (is_sph) {
-                    V3<R> cc = mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]);
-                    if constexpr (sizeof(R) == 8) cc = cc + scale<R>(ray.tm, mk<R>(R(0), R(0), R(0))); // center.at(time), sphere.h:30
-                    R t;
-                    if (sphere_t(cc, tv.u0.w[3], tv.o, tv.d, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx; }
-                    trav_goto(mem, tv, tv.i + 2);
+                // (the leaves of a BVH node are neighbours in the stream: a lane often meets two spheres in a row)
+                bool at = is_sph;
+                for (int rep = 0; rep < RT_LEAF_REPEAT; rep++) {
+                    if (at) {
+                        V3<R> cc = mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]);
+                        if constexpr (sizeof(R) == 8) cc = cc + scale<R>(ray.tm, mk<R>(R(0), R(0), R(0))); // center.at(time), sphere.h:30
+                        R t;
+                        if (sphere_t(cc, tv.u0.w[3], tv.o, tv.d, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx; }
+                        trav_goto(mem, tv, tv.i + 2);
+                    }
+                    int h = tv.hdr;
+                    asm volatile("" : "+v"(h));
+                    at = at && (h & 15) == K_SPHERE;
+                    if (popc64(lane_mask(at)) < RT_LEAF_REPEAT_MIN) break;
                 }
             } else if (action == A_AABOX) {
-                if (is_aab) {
-                    R t;
-                    if (aabox_t(tv.u0, tv.u1, tv.o, tv.inv, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx; }
-                    trav_goto(mem, tv, tv.i + 2);
+                bool at = is_aab;
+                for (int rep = 0; rep < RT_LEAF_REPEAT; rep++) {
+                    if (at) {
+                        R t;
+                        if (aabox_t(tv.u0, tv.u1, tv.o, tv.inv, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx; }
+                        trav_goto(mem, tv, tv.i + 2);
+                    }
+                    int h = tv.hdr;
+                    asm volatile("" : "+v"(h));
+                    at = at && (h & 15) == K_AABOX;
+                    if (popc64(lane_mask(at)) < RT_LEAF_REPEAT_MIN) break;
                 }
             } else if (action == A_MEDIUM) {
                 if (is_med) {
@@ -1267,9 +1291,16 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     trav_goto(mem, tv, tv.i + 2);
                 }
             } else if (action == A_OTHER) {
-                if (is_oth) {
-                    auto mxi = [&](int node_id) { return medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce); };
-                    trav_leaf_step(mem, sc, tv, ray, tmin, mxi);
+                bool at = is_oth;
+                for (int rep = 0; rep < RT_OTHER_REPEAT; rep++) {
+                    if (at) {
+                        auto mxi = [&](int node_id) { return medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce); };
+                        trav_leaf_step(mem, sc, tv, ray, tmin, mxi);
+                    }
+                    int h = tv.hdr;
+                    asm volatile("" : "+v"(h));
+                    at = at && (h & 15) >= K_QUAD && (h & 15) < K_IDLE;
+                    if (popc64(lane_mask(at)) < RT_LEAF_REPEAT_MIN) break;
                 }
             } else {
                 if (ready) {
