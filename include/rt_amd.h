@@ -229,7 +229,9 @@ int rt_scene_info(const rt_scene *scene, int32_t *out);
 
 /* Host-only (no GPU, no context): run the flattener on `desc` and report what rt_scene_upload would put on the device:
  * out[0] = record-stream units of the f32 (production) stream, out[1] = units of the f64 (parity) stream,
- * out[2] = box() lists fused into one AABOX record in the f32 stream (quad.h:103), out[3] = lights.
+ * out[2] = box() lists fused into one AABOX record in the f32 stream (quad.h:103), out[3] = lights,
+ * out[4] = translate / rotate_y instances of plain spheres emitted in world space in the f32 stream (hittable.h:45,76).
+ * `out` holds 5 values.
  * Returns RT_OK or the status rt_scene_upload would return for this description.  No reference counterpart. */
 int rt_scene_flatten_info(const rt_scene_desc *desc, int32_t *out);
 

@@ -262,6 +262,7 @@ int rt_scene_flatten_info(const rt_scene_desc *desc, int32_t *out) {
     out[1] = (int32_t)f64.stream.size();
     out[2] = f32.n_fused_boxes;
     out[3] = (int32_t)f32.lights.size();
+    out[4] = f32.n_baked_instances;
     return RT_OK;
 }
 

@@ -23,6 +23,7 @@ template <class R> struct Flat {
     std::vector<LightT<R>> lights;
     int lights_is_list = 0;
     int n_fused_boxes = 0;
+    int n_baked_instances = 0; // translate / rotate_y subtrees of plain spheres emitted in world space (f32 stream)
 };
 
 // conversions double -> R; boxes are rounded outward so that an f32 box always contains the f64 one
@@ -286,6 +287,117 @@ template <class R> class Flattener {
         return true;
     }
 
+    // ---- baked instances (f32 stream only) --------------------------------------------------------------------------
+    // translate / rotate_y over a subtree that holds nothing but static spheres whose materials need no (u, v): a sphere
+    // under a rigid transform is a sphere, so the subtree is emitted in world space (same tree, same visiting order; BOX
+    // records get the bounds of their transformed children) and the ray never has to change frames: no XF_ENTER /
+    // XF_EXIT records, no second set of inverse directions.  object -> world: p = Ry(p) + t with
+    // Ry(x, y, z) = (c x + s z, y, -s x + c z) (hittable.h:135-145), which translate and rotate_y compose within.
+    struct Rigid {
+        double c = 1, s = 0, t[3] = {0, 0, 0};
+        void apply(const double p[3], double o[3]) const {
+            o[0] = c * p[0] + s * p[2] + t[0];
+            o[1] = p[1] + t[1];
+            o[2] = -s * p[0] + c * p[2] + t[2];
+        }
+    };
+    bool bakeable(int id, int rdepth = 0) const {
+        if (rdepth > 256) return false;
+        const rt_node &n = d_.nodes[id];
+        switch (n.kind) {
+        case RT_NODE_TRANSLATE:
+        case RT_NODE_ROTATE_Y: return bakeable(n.a, rdepth + 1);
+        case RT_NODE_BVH: return bakeable(n.a, rdepth + 1) && (n.b == n.a || bakeable(n.b, rdepth + 1));
+        case RT_NODE_LIST:
+            for (int k = 0; k < n.b; k++)
+                if (!bakeable(d_.child_index[n.a + k], rdepth + 1)) return false;
+            return n.b > 0;
+        case RT_NODE_SPHERE: {
+            const rt_sphere &sp = d_.spheres[n.a];
+            return sp.mat >= 0 && sp.dcenter[0] == 0 && sp.dcenter[1] == 0 && sp.dcenter[2] == 0 &&
+                   !tex_needs_uv(d_.materials[sp.mat].tex);
+        }
+        default: return false;
+        }
+    }
+    // emits the subtree under transform `x`; lo/hi = its world bounds
+    int emit_baked(int id, const Rigid &x, int rdepth, double lo[3], double hi[3]) {
+        if (f_.stream.size() > kMaxUnits) return fail(RT_ERR_NOMEM, "flattened scene too large");
+        const rt_node &n = d_.nodes[id];
+        auto grow = [&](const double l[3], const double h[3]) {
+            for (int a = 0; a < 3; a++) {
+                lo[a] = std::fmin(lo[a], l[a]);
+                hi[a] = std::fmax(hi[a], h[a]);
+            }
+        };
+        for (int a = 0; a < 3; a++) {
+            lo[a] = INFINITY;
+            hi[a] = -INFINITY;
+        }
+        switch (n.kind) {
+        case RT_NODE_TRANSLATE: {
+            Rigid y = x; // x o translate: p -> Ry(p + off) + t
+            const double z[3] = {0, 0, 0};
+            double r0[3], r1[3];
+            Rigid rot = x;
+            rot.t[0] = rot.t[1] = rot.t[2] = 0;
+            rot.apply(n.p, r0);
+            rot.apply(z, r1);
+            for (int a = 0; a < 3; a++) y.t[a] = x.t[a] + (r0[a] - r1[a]);
+            return emit_baked(n.a, y, rdepth + 1, lo, hi);
+        }
+        case RT_NODE_ROTATE_Y: { // x o rotate: the angles add
+            Rigid y = x;
+            const double sn = n.p[0], cs = n.p[1];
+            y.c = x.c * cs - x.s * sn;
+            y.s = x.s * cs + x.c * sn;
+            return emit_baked(n.a, y, rdepth + 1, lo, hi);
+        }
+        case RT_NODE_BVH: {
+            const int self = push_units(2, id);
+            double l[3], h[3];
+            int rc = emit_baked(n.a, x, rdepth + 1, l, h);
+            if (rc) return rc;
+            grow(l, h);
+            if (n.b != n.a) {
+                rc = emit_baked(n.b, x, rdepth + 1, l, h);
+                if (rc) return rc;
+                grow(l, h);
+            }
+            R rl[3], rh[3];
+            for (int a = 0; a < 3; a++) {
+                cvt_lo(lo[a], rl[a]);
+                cvt_hi(hi[a], rh[a]);
+            }
+            f_.stream[self] = UnitT<R>{{rl[0], rh[0], rl[1], rh[1]}};
+            f_.stream[self + 1] = UnitT<R>{{rl[2], rh[2], I((int)f_.stream.size()), I(make_hdr(K_BOX, 0))}};
+            return RT_OK;
+        }
+        case RT_NODE_LIST:
+            for (int k = 0; k < n.b; k++) {
+                double l[3], h[3];
+                int rc = emit_baked(d_.child_index[n.a + k], x, rdepth + 1, l, h);
+                if (rc) return rc;
+                grow(l, h);
+            }
+            return RT_OK;
+        default: { // RT_NODE_SPHERE (bakeable() admitted nothing else)
+            const rt_sphere &sp = d_.spheres[n.a];
+            double cw[3];
+            x.apply(sp.center, cw);
+            const int off = push_units(2, id);
+            f_.stream[off] = UnitT<R>{{F(cw[0]), F(cw[1]), F(cw[2]), F(sp.radius)}};
+            f_.stream[off + 1] = UnitT<R>{{I(sp.mat), I(0), I(0), I(make_hdr(K_SPHERE, 0))}};
+            const double rr = std::fabs(sp.radius) * (1.0 + 1e-6) + 1e-6 * (std::fabs(cw[0]) + std::fabs(cw[1]) + std::fabs(cw[2]));
+            for (int a = 0; a < 3; a++) {
+                lo[a] = cw[a] - rr;
+                hi[a] = cw[a] + rr;
+            }
+            return RT_OK;
+        }
+        }
+    }
+
     // Emit the subtree of description node `id` in the reference's visiting order.
     int emit(int id, int ctx, int rdepth) {
         if (rdepth > 256) return fail(RT_ERR_INVALID, "scene graph too deep (cycle?)");
@@ -330,6 +442,11 @@ template <class R> class Flattener {
         }
         case RT_NODE_TRANSLATE:
         case RT_NODE_ROTATE_Y: {
+            if (fuse_ && ctx == 0 && bakeable(id)) {
+                double lo[3], hi[3];
+                f_.n_baked_instances++;
+                return emit_baked(id, Rigid{}, rdepth, lo, hi);
+            }
             const XformT<R> parent = f_.xforms[ctx];
             const int pdepth = ctx == 0 ? 0 : parent.depth;
             if (pdepth + 1 > MAX_XF_DEPTH)

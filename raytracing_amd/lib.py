@@ -66,11 +66,12 @@ def flatten_info(scene: abi.Scene) -> dict:
     """Host-only: what rt_scene_upload would build for `scene` (raises RtError with the status it would return)."""
     L = load()
     d = scene.desc()
-    out = np.zeros(4, dtype=np.int32)
+    out = np.zeros(5, dtype=np.int32)
     rc = L.rt_scene_flatten_info(C.byref(d), out.ctypes.data)
     if rc != abi.RT_OK:
         raise RtError(f"rt_scene_flatten_info failed with status {rc}")
-    return {"f32_units": int(out[0]), "f64_units": int(out[1]), "fused_boxes": int(out[2]), "lights": int(out[3])}
+    return {"f32_units": int(out[0]), "f64_units": int(out[1]), "fused_boxes": int(out[2]), "lights": int(out[3]),
+            "baked_instances": int(out[4])}
 
 
 class Context:
@@ -116,7 +117,7 @@ class DeviceScene:
         self.h = h
 
     def info(self) -> dict:
-        out = np.zeros(4, dtype=np.int32)
+        out = np.zeros(5, dtype=np.int32)
         self.ctx.check(self.ctx.L.rt_scene_info(self.h, out.ctypes.data), "rt_scene_info")
         return {"flat_nodes": int(out[0]), "lights": int(out[1]), "f32_bytes": int(out[2]), "f64_bytes": int(out[3])}
 
