@@ -288,8 +288,8 @@ template <class R> class Flattener {
     }
 
     // ---- baked instances (f32 stream only) --------------------------------------------------------------------------
-    // translate / rotate_y over a subtree that holds nothing but static spheres whose materials need no (u, v): a sphere
-    // under a rigid transform is a sphere, so the subtree is emitted in world space (same tree, same visiting order; BOX
+    // translate / rotate_y over a subtree that holds nothing but triangles and static spheres whose materials need no
+    // (u, v): a sphere under a rigid transform is a sphere, a triangle a triangle, so the subtree is emitted in world space (same tree, same visiting order; BOX
     // records get the bounds of their transformed children) and the ray never has to change frames: no XF_ENTER /
     // XF_EXIT records, no second set of inverse directions.  object -> world: p = Ry(p) + t with
     // Ry(x, y, z) = (c x + s z, y, -s x + c z) (hittable.h:135-145), which translate and rotate_y compose within.
@@ -317,6 +317,7 @@ template <class R> class Flattener {
             return sp.mat >= 0 && sp.dcenter[0] == 0 && sp.dcenter[1] == 0 && sp.dcenter[2] == 0 &&
                    !tex_needs_uv(d_.materials[sp.mat].tex);
         }
+        case RT_NODE_TRIANGLE: return d_.triangles[n.a].mat >= 0; // (u, v) of a triangle are barycentric: frame-independent
         default: return false;
         }
     }
@@ -381,6 +382,30 @@ template <class R> class Flattener {
                 grow(l, h);
             }
             return RT_OK;
+        case RT_NODE_TRIANGLE: {
+            const rt_triangle &t = d_.triangles[n.a];
+            Rigid rot = x;
+            rot.t[0] = rot.t[1] = rot.t[2] = 0;
+            double w0[3], w1[3], w2[3], nw[3];
+            x.apply(t.v0, w0);
+            x.apply(t.v1, w1);
+            x.apply(t.v2, w2);
+            rot.apply(t.normal, nw);
+            const double e1[3] = {w1[0] - w0[0], w1[1] - w0[1], w1[2] - w0[2]};
+            const double e2[3] = {w2[0] - w0[0], w2[1] - w0[1], w2[2] - w0[2]};
+            const int off = push_units(3, id);
+            f_.stream[off] = UnitT<R>{{F(w0[0]), F(w0[1]), F(w0[2]), F(e1[0])}};
+            f_.stream[off + 1] = UnitT<R>{{F(e1[1]), F(e1[2]), F(e2[0]), I(make_hdr(K_TRI, 0))}};
+            f_.stream[off + 2] = UnitT<R>{{F(e2[1]), F(e2[2]), I(t.mat), I(t.cull)}};
+            f_.cold[off] = UnitT<R>{{F(nw[0]), F(nw[1]), F(nw[2]), I(id)}};
+            for (int a = 0; a < 3; a++) {
+                const double mn = std::fmin(w0[a], std::fmin(w1[a], w2[a])), mx = std::fmax(w0[a], std::fmax(w1[a], w2[a]));
+                const double pad = 1e-6 * (std::fabs(mn) + std::fabs(mx)) + 5e-5; // aabb.h:77-80 pads thin boxes by 5e-5 too
+                lo[a] = mn - pad;
+                hi[a] = mx + pad;
+            }
+            return RT_OK;
+        }
         default: { // RT_NODE_SPHERE (bakeable() admitted nothing else)
             const rt_sphere &sp = d_.spheres[n.a];
             double cw[3];

@@ -107,7 +107,7 @@ def test_flattener_stream_sizes_and_box_fusion():
     # six 5-unit quads -> one 2-unit record; the translate(rotate_y(1000 spheres)) instance (cpuRenderer.cpp:369-375) is
     # emitted in world space in the f32 stream: no XF_ENTER / XF_EXIT pair for either transform
     assert info[3]["f64_units"] - info[3]["f32_units"] == 400 * (6 * 5 - 2) + 4 * 2
-    assert [info[n]["baked_instances"] for n in (1, 2, 3, 4)] == [0, 0, 1, 0]  # cornell: a box of quads; mesh: triangles
+    assert [info[n]["baked_instances"] for n in (1, 2, 3, 4)] == [0, 0, 1, 1]  # cornell's instance is a box of quads (kept: one AABOX in its own frame); mesh: the bunny
     assert info[1]["f32_units"] == info[1]["f64_units"]
     assert [info[n]["lights"] for n in (1, 2, 3, 4)] == [1, 2, 1, 2]
     # a box with one face moved is not fused
