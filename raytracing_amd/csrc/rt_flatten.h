@@ -496,7 +496,8 @@ template <class R> class Flattener {
             int rc = emit(n.a, c, rdepth + 1);
             if (rc) return rc;
             const int ex = push_units(2, id);
-            f_.stream[ex + 1] = UnitT<R>{{I(0), I(ctx), I(0), I(make_hdr(K_XF_EXIT, 0))}};
+            f_.stream[ex] = UnitT<R>{{x.p[0], x.p[1], x.p[2], R(0)}}; // the float path leaves the frame by the inverse transform
+            f_.stream[ex + 1] = UnitT<R>{{I(x.kind), I(ctx), I(0), I(make_hdr(K_XF_EXIT, 0))}};
             return RT_OK;
         }
         case RT_NODE_MEDIUM: {

@@ -543,11 +543,23 @@ RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SC &sc, Trav<R> &tv
         tv.ctx = ldi(tv.u1.w[1]);
     } else if (kind == K_XF_EXIT) {
         tv.ctx = ldi(tv.u1.w[1]);
-        const RayT<R> r = ray_in_ctx(sc, world, tv.ctx);
-        tv.o = r.o;
-        tv.d = r.d;
-        tv.inv = inv_dir(r.d);
-        if constexpr (sizeof(R) == 4) tv.noi = -(tv.o * tv.inv);
+        if constexpr (sizeof(R) == 4) {
+            // leave the frame by the inverse transform: the world-space ray need not stay in registers during traversal
+            if (ldi(tv.u1.w[0]) == XF_TRANSLATE) {
+                tv.o = tv.o + mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]);
+            } else {
+                const R s = tv.u0.w[0], c = tv.u0.w[1];
+                tv.o = mk<R>((c * tv.o.x) + (s * tv.o.z), tv.o.y, (c * tv.o.z) - (s * tv.o.x));
+                tv.d = mk<R>((c * tv.d.x) + (s * tv.d.z), tv.d.y, (c * tv.d.z) - (s * tv.d.x));
+            }
+            tv.inv = inv_dir(tv.d);
+            tv.noi = -(tv.o * tv.inv);
+        } else { // the reference's outer ray is untouched by the instance (hittable.h:53-65): restore it exactly
+            const RayT<R> r = ray_in_ctx(sc, world, tv.ctx);
+            tv.o = r.o;
+            tv.d = r.d;
+            tv.inv = inv_dir(r.d);
+        }
     }
     trav_goto(mem, tv, next);
 }
@@ -1312,6 +1324,10 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     g.k1 = a.k1;
                     g.begin_bounce(pixel, (uint32_t)smp, bounce);
                     RT_STAMP(0);
+                    if constexpr (sizeof(R) == 4) { // traversal ended in the world frame: tv holds the world-space ray
+                        ray.o = tv.o;
+                        ray.d = tv.d;
+                    }
                     V3<R> L;
                     bool alive = shade(mem, sc, cam, ray, tv.best_t, tv.best_off, tv.best_ctx, beta, L, g RT_SP_ARG);
 #ifdef RT_PROFILE_ACTIONS

@@ -20,7 +20,7 @@
 //   TRI                  3   v0.xyz, e1.x              e1.y, e1.z, e2.x, hdr              e2.y, e2.z, mat, cull
 //   MEDIUM               2   c.xyz, radius (boundary)  -1/density, mat, node_id, hdr
 //   XF_ENTER             2   p0, p1, p2, -             xf kind, ctx id, -, hdr            (translate: offset; rotate_y: sin, cos)
-//   XF_EXIT              2   -                         -, parent ctx id, -, hdr
+//   XF_EXIT              2   p0, p1, p2, -             xf kind, parent ctx id, -, hdr     (same parameters as its XF_ENTER)
 //   (end)                2   -                         -, -, -, hdr = K_READY             sentinel behind the last record
 //
 // AABOX exists in the f32 stream only: a hittable_list of six axis-aligned quads that form a closed box with one
