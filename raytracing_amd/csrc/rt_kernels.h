@@ -409,8 +409,26 @@ template <class R, class XiFn>
 RT_DEV bool medium_t(V3<R> cc, R radius, R neg_inv_density, int node_id, V3<R> ro, V3<R> rd, R tmin, R tmax, XiFn xi_fn,
                      R &t_out) {
     R t1, t2;
-    if (!sphere_t(cc, radius, ro, rd, -Const<R>::inf, Const<R>::inf, t1)) return false;
-    if (!sphere_t(cc, radius, ro, rd, t1 + R(0.0001), Const<R>::inf, t2)) return false;
+    if constexpr (sizeof(R) == 4) {
+        // both boundary hits from ONE solve of the quadratic (same conditioned form as sphere_t): over the whole line the
+        // first hit is the smaller root; the second search, over (t1 + 0.0001, inf), can only return the larger one
+        V3<R> oc = cc - ro;
+        R a = len2(rd), h = dot(rd, oc), c = len2(oc) - radius * radius;
+        R inva = m_rcp(a);
+        V3<R> perp = oc - scale<R>(h * inva, rd);
+        R disc = a * (radius * radius - len2(perp));
+        if (disc < R(0)) return false;
+        R sq = m_sqrt(disc);
+        R q = h + (h < R(0) ? -sq : sq);
+        R ta = m_div(c, q), tb = q * inva;
+        t1 = m_min(ta, tb);
+        t2 = m_max(ta, tb);
+        if (q == R(0)) { t1 = R(0); t2 = R(0); }
+        if (!(t1 + R(0.0001) < t2)) return false;
+    } else {
+        if (!sphere_t(cc, radius, ro, rd, -Const<R>::inf, Const<R>::inf, t1)) return false;
+        if (!sphere_t(cc, radius, ro, rd, t1 + R(0.0001), Const<R>::inf, t2)) return false;
+    }
     if (t1 < tmin) t1 = tmin;
     if (t2 > tmax) t2 = tmax;
     if (t1 >= t2) return false;
