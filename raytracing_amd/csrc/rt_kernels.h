@@ -1080,7 +1080,7 @@ struct RenderArgs {
     int32_t n_chunks;
     int32_t chunk_start[RT_MAX_SCHED_CHUNKS + 1];        // decreasing-size schedule (chunk c = [chunk_start[c], chunk_start[c+1]))
 };
-enum : int { A_BOX = 0, A_SPHERE = 1, A_AABOX = 2, A_MEDIUM = 3, A_OTHER = 4, A_SHADE = 5, A_COUNT = 6 };
+enum : int { A_BOX = 0, A_SPHERE = 1, A_AABOX = 2, A_MEDIUM = 3, A_OTHER = 4, A_SHADE = 5, A_COUNT = 6, A_DEAL = 7 };
 
 // Persistent megakernel.  A workgroup stages the scene stream into LDS once, then each of its waves pulls work items
 // (8x8 pixel tile x chunk of the stratified sample range) from a global cursor.  Inside an item every lane owns a pixel
@@ -1166,93 +1166,18 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
         {
             // lane state = low bits of tv.hdr: the kind of the record at the cursor, K_READY (traversal finished, waiting to
             // be shaded) or K_IDLE (no unit)
-            const int kind0 = tv.hdr & 15;
-            const unsigned long long midle = lane_mask(kind0 == K_IDLE);
-            if (midle && units_left >= 0) {
-                if (units_left > 0) {
-                    // deal units to the idle lanes: rank among the asking lanes + the item's cursor
-                    const int cur_slot = wsl(WS_CUR_SLOT), cur_s0 = wsl(WS_CUR_S0), n_item_units = wsl(WS_N_UNITS);
-                    const int cur_i0 = wsl(4 * cur_slot + WS_SLOT_I0), cur_j0 = wsl(4 * cur_slot + WS_SLOT_J0);
-                    const int slot6 = cur_slot << 6;
-                    int next_unit = n_item_units - units_left;
-                    bool need = kind0 == K_IDLE;
-                    unsigned long long m = midle;
-                    do {
-                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                        const int un = next_unit + rank;
-                        if (need && un < n_item_units) {
-                            const int p = un & 63;
-                            const int i = cur_i0 + (p & 7), j = cur_j0 + (p >> 3);
-                            if (i < cam.W && j < cam.H) { // (units of pixels beyond the image edge are skipped)
-                                need = false;
-                                pp = p | slot6;
-                                pixel = (uint32_t)(j * cam.W + i);
-                                smp = cur_s0 + (un >> 6);
-                                int sj = (int)((float)smp * (float)cam.recip_sqrt_spp); // s / sqrt_spp, s % sqrt_spp without an integer division
-                                int si = smp - sj * cam.sqrt_spp;
-                                if (si < 0) { sj--; si += cam.sqrt_spp; }
-                                if (si >= cam.sqrt_spp) { sj++; si -= cam.sqrt_spp; }
-                                Rng<R> g;
-                                g.k0 = a.k0;
-                                g.k1 = a.k1;
-                                g.begin(pixel, (uint32_t)smp);
-                                ray = get_ray(cam, i, j, si, sj, g);
-                                beta = mk<R>(R(1), R(1), R(1));
-                                bounce = 0;
-                                rays++;
-                                trav_begin(mem, tv, ray);
-                            }
-                        }
-                        next_unit += popc64(m);
-                        m = lane_mask(need);
-                    } while (m && next_unit < n_item_units);
-                    units_left = next_unit < n_item_units ? n_item_units - next_unit : 0;
-                } else {
-                // the current item has no units left: take the next accumulator slot (once the item that used it NS items
-                // ago has drained: store it first) and fetch an item into it
-                const int t = wsl(WS_CUR_SLOT) + 1 == NS ? 0 : wsl(WS_CUR_SLOT) + 1;
-                const bool t_valid = wsl(4 * t + WS_SLOT_VALID) != 0;
-                if (!(t_valid && lane_mask(kind0 != K_IDLE && (pp >> 6) == t))) {
-                    if (t_valid) flush(t, wsl(4 * t + WS_SLOT_I0), wsl(4 * t + WS_SLOT_J0), wsl(4 * t + WS_SLOT_CHUNK));
-                    int item = 0;
-                    if (lane == 0) item = (int)atomicAdd(&counters[1], 1ull);
-                    item = __builtin_amdgcn_readfirstlane(item);
-                    const int n_tiles = a.tiles_x * a.tiles_y;
-                    const bool got = item < n_tiles * a.n_chunks; // the cursor is finite: every wave sees its end
-                    const int chunk = item / n_tiles, tile = item - chunk * n_tiles;
-                    const int tj = tile / a.tiles_x, ti = tile - tj * a.tiles_x;
-                    int s0, s1;
-                    if (a.chunk_size > 0) {
-                        s0 = a.s_begin + chunk * a.chunk_size;
-                        s1 = s0 + a.chunk_size;
-                        if (s1 > a.s_end) s1 = a.s_end;
-                    } else {
-                        s0 = a.chunk_start[got ? chunk : 0];
-                        s1 = a.chunk_start[got ? chunk + 1 : 0];
-                    }
-                    const int n_new = got && cam.max_depth > 0 ? (s1 - s0) << 6 : 0; // max_depth <= 0: every sample is black (camera.h:294)
-                    if (lane == 0) {
-                        ws[4 * t + WS_SLOT_I0] = ti * 8; ws[4 * t + WS_SLOT_J0] = tj * 8; ws[4 * t + WS_SLOT_CHUNK] = chunk;
-                        ws[4 * t + WS_SLOT_VALID] = got ? 1 : 0;
-                        ws[WS_CUR_SLOT] = t; ws[WS_CUR_S0] = s0; ws[WS_N_UNITS] = n_new;
-                    }
-                    units_left = got ? n_new : -1;
-                }
-                }
-            }
             const int kind = tv.hdr & 15;
             const bool is_box = kind == K_BOX, is_sph = kind == K_SPHERE, is_aab = kind == K_AABOX, is_med = kind == K_MEDIUM;
             const bool is_oth = kind >= K_QUAD && kind < K_IDLE; // quad, triangle, moving sphere, instance boundary
             const bool ready = kind == K_READY;
             const unsigned long long mb = lane_mask(is_box), ms = lane_mask(is_sph), ma = lane_mask(is_aab), mm = lane_mask(is_med),
                                      mo = lane_mask(is_oth), mr = lane_mask(ready);
-            if (!(mb | ms | ma | mm | mo | mr)) { // nothing in flight: the next trip deals or fetches, or the wave is done
-                if (units_left < 0) break;
-            } else {
+            if (!(mb | ms | ma | mm | mo | mr) && units_left < 0) break; // nothing in flight, no items left: the wave is done
+            {
             // Run ONE block per trip: shading once enough lanes wait for it, else the record kind with the largest weighted
             // number of waiting lanes (score = count * weight, block id in the low bits -> one max chain).
             const int nr = popc64(mr);
-            int action = A_SHADE;
+            int action = (mb | ms | ma | mm | mo | mr) ? A_SHADE : A_DEAL;
             if (nr < RT_SHADE_T) {
                 const unsigned sb = ((unsigned)(popc64(mb) * RT_W_BOX) << 3) | A_BOX, ss = ((unsigned)(popc64(ms) * RT_W_LEAF) << 3) | A_SPHERE,
                                sa = ((unsigned)(popc64(ma) * RT_W_LEAF) << 3) | A_AABOX, sm = ((unsigned)(popc64(mm) * RT_W_LEAF) << 3) | A_MEDIUM,
@@ -1332,7 +1257,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     at = at && (h & 15) >= K_QUAD && (h & 15) < K_IDLE;
                     if (popc64(lane_mask(at)) < RT_LEAF_REPEAT_MIN) break;
                 }
-            } else {
+            } else if (action == A_SHADE) {
                 if (ready) {
 #ifdef RT_PROFILE_ACTIONS
                     sp.last = __builtin_amdgcn_s_memtime();
@@ -1371,6 +1296,84 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     sp_tail += __builtin_amdgcn_s_memtime() - sp.last;
                 }
 #endif
+            }
+            // units for the lanes without one: after a shading trip (paths have ended) or when nothing is in flight
+            if (action == A_SHADE || action == A_DEAL) {
+            const int kind0 = tv.hdr & 15;
+            const unsigned long long midle = lane_mask(kind0 == K_IDLE);
+            if (midle && units_left >= 0) {
+                if (units_left == 0) {
+                // the current item has no units left: take the next accumulator slot (once the item that used it NS items
+                // ago has drained: store it first) and fetch an item into it
+                const int t = wsl(WS_CUR_SLOT) + 1 == NS ? 0 : wsl(WS_CUR_SLOT) + 1;
+                const bool t_valid = wsl(4 * t + WS_SLOT_VALID) != 0;
+                if (!(t_valid && lane_mask(kind0 != K_IDLE && (pp >> 6) == t))) {
+                    if (t_valid) flush(t, wsl(4 * t + WS_SLOT_I0), wsl(4 * t + WS_SLOT_J0), wsl(4 * t + WS_SLOT_CHUNK));
+                    int item = 0;
+                    if (lane == 0) item = (int)atomicAdd(&counters[1], 1ull);
+                    item = __builtin_amdgcn_readfirstlane(item);
+                    const int n_tiles = a.tiles_x * a.tiles_y;
+                    const bool got = item < n_tiles * a.n_chunks; // the cursor is finite: every wave sees its end
+                    const int chunk = item / n_tiles, tile = item - chunk * n_tiles;
+                    const int tj = tile / a.tiles_x, ti = tile - tj * a.tiles_x;
+                    int s0, s1;
+                    if (a.chunk_size > 0) {
+                        s0 = a.s_begin + chunk * a.chunk_size;
+                        s1 = s0 + a.chunk_size;
+                        if (s1 > a.s_end) s1 = a.s_end;
+                    } else {
+                        s0 = a.chunk_start[got ? chunk : 0];
+                        s1 = a.chunk_start[got ? chunk + 1 : 0];
+                    }
+                    const int n_new = got && cam.max_depth > 0 ? (s1 - s0) << 6 : 0; // max_depth <= 0: every sample is black (camera.h:294)
+                    if (lane == 0) {
+                        ws[4 * t + WS_SLOT_I0] = ti * 8; ws[4 * t + WS_SLOT_J0] = tj * 8; ws[4 * t + WS_SLOT_CHUNK] = chunk;
+                        ws[4 * t + WS_SLOT_VALID] = got ? 1 : 0;
+                        ws[WS_CUR_SLOT] = t; ws[WS_CUR_S0] = s0; ws[WS_N_UNITS] = n_new;
+                    }
+                    units_left = got ? n_new : -1;
+                }
+                }
+                if (units_left > 0) {
+                    // deal units to the idle lanes: rank among the asking lanes + the item's cursor
+                    const int cur_slot = wsl(WS_CUR_SLOT), cur_s0 = wsl(WS_CUR_S0), n_item_units = wsl(WS_N_UNITS);
+                    const int cur_i0 = wsl(4 * cur_slot + WS_SLOT_I0), cur_j0 = wsl(4 * cur_slot + WS_SLOT_J0);
+                    const int slot6 = cur_slot << 6;
+                    int next_unit = n_item_units - units_left;
+                    bool need = kind0 == K_IDLE;
+                    unsigned long long m = midle;
+                    do {
+                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        const int un = next_unit + rank;
+                        if (need && un < n_item_units) {
+                            const int p = un & 63;
+                            const int i = cur_i0 + (p & 7), j = cur_j0 + (p >> 3);
+                            if (i < cam.W && j < cam.H) { // (units of pixels beyond the image edge are skipped)
+                                need = false;
+                                pp = p | slot6;
+                                pixel = (uint32_t)(j * cam.W + i);
+                                smp = cur_s0 + (un >> 6);
+                                int sj = (int)((float)smp * (float)cam.recip_sqrt_spp); // s / sqrt_spp, s % sqrt_spp without an integer division
+                                int si = smp - sj * cam.sqrt_spp;
+                                if (si < 0) { sj--; si += cam.sqrt_spp; }
+                                if (si >= cam.sqrt_spp) { sj++; si -= cam.sqrt_spp; }
+                                Rng<R> g;
+                                g.k0 = a.k0;
+                                g.k1 = a.k1;
+                                g.begin(pixel, (uint32_t)smp);
+                                ray = get_ray(cam, i, j, si, sj, g);
+                                beta = mk<R>(R(1), R(1), R(1));
+                                bounce = 0;
+                                rays++;
+                                trav_begin(mem, tv, ray);
+                            }
+                        }
+                        next_unit += popc64(m);
+                        m = lane_mask(need);
+                    } while (m && next_unit < n_item_units);
+                    units_left = next_unit < n_item_units ? n_item_units - next_unit : 0;
+                }
+            }
             }
 #ifdef RT_PROFILE_ACTIONS
             { // diagnostic build only: cycles, trips and active lanes per action -> counters[4 + 3*action ...]
