@@ -45,7 +45,14 @@ def test_trace_batch_f32_close_to_reference(scenes, n):
     rays, xi, hits = fx.trace(n)
     got = scenes[n].trace_batch(rays, xi, abi.RT_PREC_F32)
     same = got["prim"] == hits["prim"]
-    assert (~same).sum() <= 0.003 * len(rays)
+    # ids differ only (a) where two primitives are hit at the same distance -- the shared edge of two faces of a box: the
+    # same t to float precision, float rounding decides the winner (tools/trace_mismatch.py lists them) -- and (b) on a
+    # handful of rays that graze an edge or start on a surface
+    both = ~same & (got["prim"] >= 0) & (hits["prim"] >= 0)
+    with np.errstate(invalid="ignore"):  # inf - inf on rays that miss in both
+        tie = both & (np.abs(got["t"] - hits["t"]) <= 1e-5 * np.abs(hits["t"]))
+    assert (~same).sum() <= 0.005 * len(rays)
+    assert (~same & ~tie).sum() <= 0.002 * len(rays)
     primary = np.arange(len(rays)) < 64 * 36
     hit = same & (hits["prim"] >= 0) & primary
     kinds = fx.scene(n).nodes["kind"][hits["prim"][hit]]
