@@ -315,12 +315,12 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
         if (stats) *stats = rt_stats{0, 0, 0.0};
         return RT_OK;
     }
-    // Work decomposition: a work item = (8x8 pixel tile, chunk of the sample range); waves pull items from a cursor in
+    // Work decomposition: a work item = (8 x RT_TILE_H pixel tile, chunk of the sample range); waves pull items from a cursor in
     // chunk-major order.  Default: a DECREASING-size schedule (each chunk takes a half / a third of what is left, down to a minimum),
     // so the bulk of the samples runs in long items (lanes regenerate paths inside an item; a short item wastes lanes while
     // its last paths finish) and the kernel ends on short ones (the end-of-kernel imbalance is one short item per wave).
     // params->sample_chunks > 0 forces that many equal chunks instead.
-    const int tiles = ((cam->image_width + 7) / 8) * ((cam->image_height + 7) / 8);
+    const int tiles = ((cam->image_width + 7) / 8) * ((cam->image_height + RT_TILE_H - 1) / RT_TILE_H);
     RenderLaunch rl{};
     int n_chunks = params->sample_chunks;
     const int wave_slots = ctx->n_cus * 16;

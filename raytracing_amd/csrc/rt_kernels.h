@@ -1090,7 +1090,7 @@ enum : int { A_BOX = 0, A_SPHERE = 1, A_AABOX = 2, A_MEDIUM = 3, A_OTHER = 4, A_
 // need (64-lane divergence is the limiter of this workload: see DESIGN.md, profiles/).
 // per-wave item state (32 ints behind the wave's accumulators):
 // slot k: ws[4k .. 4k+3] = tile origin i0, j0, chunk, valid; then the dealing item's slot, first sample and unit count
-enum : int { WS_SLOT_I0 = 0, WS_SLOT_J0 = 1, WS_SLOT_CHUNK = 2, WS_SLOT_VALID = 3, WS_CUR_SLOT = 24, WS_CUR_S0 = 25, WS_N_UNITS = 26 };
+enum : int { WS_SLOT_I0 = 0, WS_SLOT_J0 = 1, WS_SLOT_CHUNK = 2, WS_SLOT_VALID = 3, WS_CUR_SLOT = 40, WS_CUR_S0 = 41, WS_N_UNITS = 42 };
 
 template <class R, bool ALL_LDS, bool TAB_LDS, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT<R> cam_arg, RenderArgs a_arg, float *__restrict__ out,
@@ -1126,17 +1126,17 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     ShadeProf sp{};
     unsigned long long sp_tail = 0, prof_idle = 0, prof_ready = 0, prof_all = 0, prof_tail = 0;
 #endif
-    // Work: an item = (8x8 pixel tile, chunk of the sample range) = 64 x samples UNITS, unit u = sample s0 + u / 64 of the
-    // tile's pixel u % 64.  Lanes do not own pixels: a lane whose path has ended takes the next unit (wave-level dealing:
+    // Work: an item = (8 x 4 pixel tile, chunk of the sample range) = 32 x samples UNITS, unit u = sample s0 + u / 32 of the
+    // tile's pixel u % 32.  Lanes do not own pixels: a lane whose path has ended takes the next unit (wave-level dealing:
     // rank among the asking lanes + the wave's cursor), so a pixel with short paths never leaves its lane idle while a
     // neighbour grinds through long ones; when the item has no units left the wave fetches the next item and keeps
     // dealing while the old item's last paths finish (two items in flight: `cur` deals, `prev` drains).  The RNG is keyed
     // by (pixel, sample), so the image does not depend on who traces what; a finished path is added to its item's
-    // 64-pixel accumulator in LDS (ds_add: the order of the adds is this wave's own deterministic schedule).
+    // per-pixel accumulator in LDS (ds_add: the order of the adds is this wave's own deterministic schedule).
     constexpr int NS = LdsLayout<R>::item_slots;
-    static_assert(NS >= 2 && NS <= 4, "slot id: 2 bits of pp; item state: 32 ints");
-    for (int k = 0; k < 3 * NS; k++) acc[lane + 64 * k] = R(0);
-    if (lane < 32) ws[lane] = 0;
+    constexpr int TPX = LdsLayout<R>::tile_px, TSH = LdsLayout<R>::tile_shift; // pixels per item, log2 of it
+    for (int k = lane; k < LdsLayout<R>::wave_acc; k += 64) acc[k] = R(0);
+    if (lane < 48) ws[lane] = 0;
     RayT<R> ray;
     V3<R> beta;
     Trav<R> tv;
@@ -1152,13 +1152,13 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     // every path of an item has ended: lane p stores pixel p's sums and clears the accumulator for its next item
     auto flush = [&](int slot, int i0, int j0, int chunk) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        R *const b = acc + slot * 192 + lane * 3;
+        R *const b = acc + slot * LdsLayout<R>::slot_acc + (lane & (TPX - 1)) * 3;
         const int i = i0 + (lane & 7), j = j0 + (lane >> 3);
-        if (i < cam.W && j < cam.H) {
+        if (lane < TPX && i < cam.W && j < cam.H) {
             const size_t o = ((size_t)chunk * cam.H * cam.W + (size_t)j * cam.W + i) * 3;
             out[o] = (float)b[0]; out[o + 1] = (float)b[1]; out[o + 2] = (float)b[2];
         }
-        b[0] = R(0); b[1] = R(0); b[2] = R(0);
+        if (lane < TPX) { b[0] = R(0); b[1] = R(0); b[2] = R(0); }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     };
 
@@ -1307,7 +1307,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                 // ago has drained: store it first) and fetch an item into it
                 const int t = wsl(WS_CUR_SLOT) + 1 == NS ? 0 : wsl(WS_CUR_SLOT) + 1;
                 const bool t_valid = wsl(4 * t + WS_SLOT_VALID) != 0;
-                if (!(t_valid && lane_mask(kind0 != K_IDLE && (pp >> 6) == t))) {
+                if (!(t_valid && lane_mask(kind0 != K_IDLE && (pp >> TSH) == t))) {
                     if (t_valid) flush(t, wsl(4 * t + WS_SLOT_I0), wsl(4 * t + WS_SLOT_J0), wsl(4 * t + WS_SLOT_CHUNK));
                     int item = 0;
                     if (lane == 0) item = (int)atomicAdd(&counters[1], 1ull);
@@ -1325,9 +1325,9 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         s0 = a.chunk_start[got ? chunk : 0];
                         s1 = a.chunk_start[got ? chunk + 1 : 0];
                     }
-                    const int n_new = got && cam.max_depth > 0 ? (s1 - s0) << 6 : 0; // max_depth <= 0: every sample is black (camera.h:294)
+                    const int n_new = got && cam.max_depth > 0 ? (s1 - s0) << TSH : 0; // max_depth <= 0: every sample is black (camera.h:294)
                     if (lane == 0) {
-                        ws[4 * t + WS_SLOT_I0] = ti * 8; ws[4 * t + WS_SLOT_J0] = tj * 8; ws[4 * t + WS_SLOT_CHUNK] = chunk;
+                        ws[4 * t + WS_SLOT_I0] = ti * 8; ws[4 * t + WS_SLOT_J0] = tj * LdsLayout<R>::tile_h; ws[4 * t + WS_SLOT_CHUNK] = chunk;
                         ws[4 * t + WS_SLOT_VALID] = got ? 1 : 0;
                         ws[WS_CUR_SLOT] = t; ws[WS_CUR_S0] = s0; ws[WS_N_UNITS] = n_new;
                     }
@@ -1338,7 +1338,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     // deal units to the idle lanes: rank among the asking lanes + the item's cursor
                     const int cur_slot = wsl(WS_CUR_SLOT), cur_s0 = wsl(WS_CUR_S0), n_item_units = wsl(WS_N_UNITS);
                     const int cur_i0 = wsl(4 * cur_slot + WS_SLOT_I0), cur_j0 = wsl(4 * cur_slot + WS_SLOT_J0);
-                    const int slot6 = cur_slot << 6;
+                    const int slot6 = cur_slot << TSH;
                     int next_unit = n_item_units - units_left;
                     bool need = kind0 == K_IDLE;
                     unsigned long long m = midle;
@@ -1346,13 +1346,13 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                         const int un = next_unit + rank;
                         if (need && un < n_item_units) {
-                            const int p = un & 63;
+                            const int p = un & (TPX - 1);
                             const int i = cur_i0 + (p & 7), j = cur_j0 + (p >> 3);
                             if (i < cam.W && j < cam.H) { // (units of pixels beyond the image edge are skipped)
                                 need = false;
                                 pp = p | slot6;
                                 pixel = (uint32_t)(j * cam.W + i);
-                                smp = cur_s0 + (un >> 6);
+                                smp = cur_s0 + (un >> TSH);
                                 int sj = (int)((float)smp * (float)cam.recip_sqrt_spp); // s / sqrt_spp, s % sqrt_spp without an integer division
                                 int si = smp - sj * cam.sqrt_spp;
                                 if (si < 0) { sj--; si += cam.sqrt_spp; }

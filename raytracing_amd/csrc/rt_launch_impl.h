@@ -25,7 +25,7 @@ hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const Rende
     for (int k = 0; k <= RT_MAX_SCHED_CHUNKS; k++) a.chunk_start[k] = rl.chunk_start[k];
     if (rl.chunk_size == 0 && (rl.n_chunks < 1 || rl.n_chunks > RT_MAX_SCHED_CHUNKS)) return hipErrorInvalidValue;
     a.tiles_x = (cam.W + 7) / 8;
-    a.tiles_y = (cam.H + 7) / 8;
+    a.tiles_y = (cam.H + LdsLayout<R>::tile_h - 1) / LdsLayout<R>::tile_h;
     const size_t lds = (size_t)sc.lds_units * sizeof(UnitT<R>) + (sc.tab_in_lds ? (size_t)sc.tab_bytes : 0);
     if (sc.lds_units < 0 || sc.lds_units > sc.n_units || lds > (size_t)C::lds_bytes || (sc.tab_bytes & 15)) return hipErrorInvalidValue;
     const long long items = (long long)a.tiles_x * a.tiles_y * rl.n_chunks;

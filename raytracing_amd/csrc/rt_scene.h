@@ -191,10 +191,13 @@ template <class R> struct SceneT { // device pointers; passed to kernels by valu
 
 // LDS map of a workgroup (all offsets are compile-time constants, so no register holds them):
 //   [0, stream_off)            per wave: item_slots accumulator slots (items in flight) x 64 pixels x RGB, then the
-//                              wave's item state (32 ints)
+//                              wave's item state (48 ints)
 //   [stream_off, ...)          the leading lds_units units of the record stream, then (when they fit) the shading tables
 #ifndef RT_ITEM_SLOTS
-#define RT_ITEM_SLOTS 4
+#define RT_ITEM_SLOTS 8
+#endif
+#ifndef RT_TILE_H // an item's pixel tile is 8 wide and RT_TILE_H (8 or 4) high
+#define RT_TILE_H 4
 #endif
 #ifndef RT_F32_BLOCK
 #define RT_F32_BLOCK 1024
@@ -203,8 +206,11 @@ template <class R> struct LdsLayout {
     static constexpr int block = sizeof(R) == 4 ? RT_F32_BLOCK : 512; // f32: 16 waves/CU, <= 128 VGPRs; f64 (parity path): 8 waves
     static constexpr int waves = block / 64;
     static constexpr int item_slots = RT_ITEM_SLOTS;                           // items in flight per wave
-    static constexpr int wave_acc = item_slots * 64 * 3;                       // accumulator scalars per wave
-    static constexpr int wave_stride = wave_acc * (int)sizeof(R) + 32 * 4;     // bytes per wave (+ 32 ints of item state)
+    static constexpr int tile_h = RT_TILE_H, tile_px = 8 * tile_h, tile_shift = tile_h == 8 ? 6 : 5;
+    static constexpr int slot_acc = tile_px * 3;                               // accumulator scalars per slot
+    static constexpr int wave_acc = item_slots * slot_acc;                     // accumulator scalars per wave
+    static constexpr int wave_stride = wave_acc * (int)sizeof(R) + 48 * 4;     // bytes per wave (+ 48 ints of item state)
+    static_assert((tile_h == 8 || tile_h == 4) && item_slots >= 2 && item_slots <= 8, "tile / slot geometry");
     static constexpr int wave_off = 0;
     static constexpr int stream_off = wave_off + waves * wave_stride;
     static constexpr int total_bytes = sizeof(R) == 4 ? 160 * 1024 - 512 : 160 * 1024 - 512 - 16 * 1024;
