@@ -1083,7 +1083,7 @@ struct RenderArgs {
 enum : int { A_BOX = 0, A_SPHERE = 1, A_AABOX = 2, A_MEDIUM = 3, A_OTHER = 4, A_SHADE = 5, A_COUNT = 6, A_DEAL = 7 };
 
 // Persistent megakernel.  A workgroup stages the scene stream into LDS once, then each of its waves pulls work items
-// (8x8 pixel tile x chunk of the stratified sample range) from a global cursor.  Inside an item every lane owns a pixel
+// (8x4 pixel tile x chunk of the stratified sample range) from a global cursor.  Inside an item every lane owns a pixel
 // and runs its samples back to back (path regeneration).  The wave is a three-state machine: at any time a lane is at
 // a BOX record, at a leaf record, or waiting to be shaded; each trip of the loop runs ONE of the three code blocks,
 // chosen wave-uniformly, so the hot BOX step is never serialised behind leaf or shading code that only a few lanes
@@ -1113,7 +1113,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     const Mem<R, ALL_LDS> mem{sc_arg.stream, sc_arg.lds_units};
     const int lane = threadIdx.x & 63;
     const R tmin = R(0.001);
-    // this wave's accumulators (two slots = items in flight, x 64 pixels x RGB) and item state
+    // this wave's accumulators (item_slots slots = items in flight, x tile_px pixels x RGB) and item state
     R *const acc = reinterpret_cast<R *>(rt_smem + LdsLayout<R>::wave_off + (threadIdx.x >> 6) * LdsLayout<R>::wave_stride);
     int *const ws = reinterpret_cast<int *>(acc + LdsLayout<R>::wave_acc);
     unsigned rays = 0;

@@ -190,7 +190,7 @@ template <class R> struct SceneT { // device pointers; passed to kernels by valu
 };
 
 // LDS map of a workgroup (all offsets are compile-time constants, so no register holds them):
-//   [0, stream_off)            per wave: item_slots accumulator slots (items in flight) x 64 pixels x RGB, then the
+//   [0, stream_off)            per wave: item_slots accumulator slots (items in flight) x tile_px pixels x RGB, then the
 //                              wave's item state (48 ints)
 //   [stream_off, ...)          the leading lds_units units of the record stream, then (when they fit) the shading tables
 #ifndef RT_ITEM_SLOTS
