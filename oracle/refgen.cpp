@@ -533,6 +533,21 @@ static void on_render(camera &cam, const hittable &world, const hittable &lights
 // usage: refgen <mode> <scene 1..4|5(bounce frame)> <W> <H> <spp> <depth> <use_bvh 0|1> <out> [seed|extra_rays] [frame]
 #undef main
 int main(int argc, char **argv) {
+    if (argc == 4 && std::string(argv[1]) == "teximg") { // refgen teximg <image file> <out>: the reference's rtw_image::load
+        rtw_image img;                                   // (stb_image_utils.h:46-55) -> "RTWTEX01", w, h, linear RGB8
+        if (!img.load(argv[2])) {
+            fprintf(stderr, "refgen: the reference loader rejects %s\n", argv[2]);
+            return 3;
+        }
+        FILE *f = fopen(argv[3], "wb");
+        if (!f) return 2;
+        const int32_t wh[2] = {img.image_width, img.image_height};
+        fwrite("RTWTEX01", 1, 8, f);
+        fwrite(wh, 4, 2, f);
+        fwrite(img.bdata, 1, (size_t)wh[0] * wh[1] * 3, f);
+        fclose(f);
+        return 0;
+    }
     if (argc < 9) {
         fprintf(stderr, "usage: refgen dump|trace|render scene W H spp depth use_bvh out [seed|extra_rays] [frame]\n");
         return 2;

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librtamd_host.so")
 ASSET_DIR = os.path.join(_HERE, "assets")
 EXPORTS = ["rtamd_host_build_scene", "rtamd_host_scene_desc", "rtamd_host_scene_camera", "rtamd_host_scene_save", "rtamd_host_scene_animation",
-           "rtamd_host_scene_free"]
+           "rtamd_host_load_image", "rtamd_host_scene_free"]
 _lib = None
 
 
@@ -33,6 +33,8 @@ def load() -> C.CDLL:
         L.rtamd_host_scene_save.argtypes = [C.c_void_p, C.c_char_p]
         L.rtamd_host_scene_animation.restype = C.c_int
         L.rtamd_host_scene_animation.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.rtamd_host_load_image.restype = C.c_int
+        L.rtamd_host_load_image.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
         L.rtamd_host_scene_free.restype = None
         L.rtamd_host_scene_free.argtypes = [C.c_void_p]
         _lib = L
@@ -75,3 +77,17 @@ def build_scene(scene: int, image_width: int, image_height: int, samples_per_pix
     finally:
         L.rtamd_host_scene_free(h)
     return sc
+
+
+def load_image(path: str) -> np.ndarray:
+    """rtw_image::load (stb_image_utils.h:46-55) for one file: (height, width, 3) linearised RGB8 texels.  JPEGs are
+    decoded by include/rtamd/jpeg_baseline.h; other formats are read from "<path>.rtwtex".  Raises RuntimeError for a
+    file that is missing, unsupported (progressive JPEG ...) or corrupt."""
+    L = load()
+    w, h = C.c_int(0), C.c_int(0)
+    if L.rtamd_host_load_image(path.encode(), C.byref(w), C.byref(h), None, 0) != 0:
+        raise RuntimeError(f"cannot load image {path!r} (see stderr)")
+    out = np.zeros((h.value, w.value, 3), dtype=np.uint8)
+    if L.rtamd_host_load_image(path.encode(), C.byref(w), C.byref(h), out.ctypes.data, out.size) != 0:
+        raise RuntimeError(f"cannot load image {path!r} (see stderr)")
+    return out

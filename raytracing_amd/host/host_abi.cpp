@@ -53,6 +53,19 @@ int rtamd_host_scene_animation(const rtamd_host_scene *s, int method, rt_camera 
     return n;
 }
 
+int rtamd_host_load_image(const char *path, int *width, int *height, unsigned char *out, size_t cap) {
+    if (!path || !width || !height) return RT_ERR_INVALID;
+    rtw_image img;
+    if (!img.load(path)) return RT_ERR_INVALID;
+    *width = img.width();
+    *height = img.height();
+    if (out) {
+        if (cap < img.bytes().size()) return RT_ERR_INVALID;
+        std::memcpy(out, img.bytes().data(), img.bytes().size());
+    }
+    return RT_OK;
+}
+
 int rtamd_host_scene_save(const rtamd_host_scene *s, const char *path) {
     if (!s || !path) return RT_ERR_INVALID;
     return s->flat.save(path, &s->cam) ? RT_OK : RT_ERR_INVALID;
