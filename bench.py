@@ -99,6 +99,13 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt, kern_ms = float(t[0]), float(t[1])
+    # rays traced per frame (SURVEY 8d asks for rays/s too): one more, untimed, launch that reads the counter back
+    st = ds.render_device(cam, accum.data_ptr(), seed=1984, s_begin=s0, s_end=s1, precision=abi.RT_PREC_F32, stream=stream,
+                          want_stats=True)
+    rays = torch.tensor([float(st["rays"])], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    rays = float(rays[0])
 
     if rank == 0:
         samples = W * H * n * n
@@ -111,6 +118,7 @@ def main():
             "metric": "Msamples/s (node), final_scene 1080p @1000 spp", "value": round(samples / sec_per_frame / 1e6, 3),
             "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(sec_per_frame * 1e3, 3), "sec_per_frame": round(sec_per_frame, 4),
+            "grays_per_s": round(rays / sec_per_frame / 1e9, 3), "rays_per_sample": round(rays / samples, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"final_scene {W}x{H}, {a.spp} spp (-> {n * n} stratified samples), depth {a.depth}, "
                                    f"spp range split over {world} GPU(s) + RCCL reduce", "samples_per_frame": samples},

@@ -1,11 +1,12 @@
-// jpeg_baseline.h -- baseline / extended-sequential Huffman JPEG decoder for image_texture files.
+// jpeg_baseline.h -- Huffman JPEG decoder (baseline, extended sequential, progressive; 8-bit) for image_texture files
+// (SURVEY §8f rank 4).
 //
 // The reference reads textures through the vendored stb_image (stb_image_utils.h:46-55: stbi_loadf -> linear float ->
 // bytes).  The texels feed the render, so this decoder reproduces that pipeline's ARITHMETIC bit for bit -- the
 // fixed-point inverse DCT (constants x4096, +512 >>10 after the column pass, +65536+(128<<17) >>17 after the row pass),
 // the chroma upsampling filters (3:1 taps, centred), the 20-bit fixed-point YCbCr -> RGB conversion -- and is checked
 // against texels produced by the compiled reference (tests/test_jpeg_decode.py, tests/golden/jpeg/).  What it does not
-// read fails loudly: progressive, arithmetic-coded, 12-bit and CMYK files.
+// read fails loudly: arithmetic-coded, lossless, 12-bit and CMYK files.
 //
 // Header-only, host code, no dependencies.  ITU T.81 section numbers are cited where a step follows the standard.
 #ifndef RTAMD_JPEG_BASELINE_H
@@ -76,6 +77,14 @@ struct Bits {
         acc <<= 1;
         n--;
         return b;
+    }
+    int raw(int s) { // s raw bits, MSB first (T.81 F.2.2.4 RECEIVE)
+        if (s == 0) return 0;
+        if (n < s) fill();
+        int v = (int)(acc >> (32 - s));
+        acc <<= s;
+        n -= s;
+        return v;
     }
     // T.81 F.2.2.1 RECEIVE + EXTEND
     int receive_extend(int s) {
@@ -171,6 +180,8 @@ struct Component {
     int w2 = 0, h2 = 0; // samples, padded to whole MCUs
     int dc_pred = 0;
     std::vector<uint8_t> data;
+    std::vector<int16_t> coef; // progressive: (w2/8) x (h2/8) blocks of 64 coefficients, natural order, not dequantised
+    int blocks_w = 0;
 };
 
 // Chroma upsampling of one output row (stb_image.h:2839-2910, 3029): near / far are the two source rows that bracket it.
@@ -238,7 +249,8 @@ struct Decoder {
     Huff dc[4], ac[4];
     Component comp[3];
     int ncomp = 0, width = 0, height = 0, h_max = 1, v_max = 1, mcus_x = 0, mcus_y = 0, restart_interval = 0;
-    bool have_frame = false;
+    bool have_frame = false, progressive = false;
+    int ss = 0, se = 63, ah = 0, al = 0, eob_run = 0; // progressive scan parameters (T.81 G.1)
     Bits bits;
 
     Decoder(const uint8_t *d, size_t n) : p(d), end(d + n) {}
@@ -310,6 +322,10 @@ struct Decoder {
             c.w2 = mcus_x * c.h * 8;
             c.h2 = mcus_y * c.v * 8;
             c.data.assign((size_t)c.w2 * c.h2, 0);
+            if (progressive) {
+                c.blocks_w = c.w2 / 8;
+                c.coef.assign((size_t)c.w2 * c.h2, 0);
+            }
         }
         have_frame = true;
         return true;
@@ -341,8 +357,112 @@ struct Decoder {
         return true;
     }
 
+    // Progressive scans (T.81 G.1.2), coefficient values as the reference's decoder keeps them (stb_image.h:1748-1890):
+    // DC: first pass value << al, refinement adds one bit.
+    bool prog_dc(Component &c, int16_t *d) {
+        if (se != 0) return fail("can't merge dc and ac");
+        if (ah == 0) {
+            std::memset(d, 0, 64 * sizeof(int16_t));
+            const int t = bits.decode(dc[c.td]);
+            if (t < 0 || t > 15) return fail("bad huffman code");
+            c.dc_pred += bits.receive_extend(t);
+            d[0] = (int16_t)(c.dc_pred * (1 << al));
+        } else if (bits.bit()) {
+            d[0] = (int16_t)(d[0] + (int16_t)(1 << al));
+        }
+        return true;
+    }
+    // AC: spectral band [ss, se]; first pass with end-of-band runs, refinement with correction bits for the
+    // coefficients that are already non-zero.
+    bool prog_ac(Component &c, int16_t *d) {
+        if (ss == 0) return fail("can't merge dc and ac");
+        const Huff &h = ac[c.ta];
+        if (ah == 0) {
+            if (eob_run) {
+                --eob_run;
+                return true;
+            }
+            int k = ss;
+            do {
+                const int rs = bits.decode(h);
+                if (rs < 0) return fail("bad huffman code");
+                const int s = rs & 15, r = rs >> 4;
+                if (s == 0) {
+                    if (r < 15) {
+                        eob_run = (1 << r);
+                        if (r) eob_run += bits.raw(r);
+                        --eob_run;
+                        break;
+                    }
+                    k += 16;
+                } else {
+                    k += r;
+                    if (k > 63) return fail("bad huffman code");
+                    d[k_zigzag[k++]] = (int16_t)(bits.receive_extend(s) * (1 << al));
+                }
+            } while (k <= se);
+            return true;
+        }
+        const int16_t bit = (int16_t)(1 << al);
+        auto refine = [&](int16_t &v) { // one correction bit for a non-zero coefficient
+            if (bits.bit() && (v & bit) == 0) v = (int16_t)(v > 0 ? v + bit : v - bit);
+        };
+        if (eob_run) {
+            --eob_run;
+            for (int k = ss; k <= se; k++) {
+                int16_t &v = d[k_zigzag[k]];
+                if (v != 0) refine(v);
+            }
+            return true;
+        }
+        int k = ss;
+        do {
+            const int rs = bits.decode(h);
+            if (rs < 0) return fail("bad huffman code");
+            int s = rs & 15, r = rs >> 4;
+            if (s == 0) {
+                if (r < 15) {
+                    eob_run = (1 << r) - 1;
+                    if (r) eob_run += bits.raw(r);
+                    r = 64; // finish the band: only correction bits from here
+                }
+                // r == 15: sixteen zero coefficients are skipped below (a run of 15, then the "new" value 0)
+            } else {
+                if (s != 1) return fail("bad huffman code");
+                s = bits.bit() ? bit : -bit;
+            }
+            while (k <= se) {
+                int16_t &v = d[k_zigzag[k++]];
+                if (v != 0) {
+                    refine(v);
+                } else {
+                    if (r == 0) {
+                        v = (int16_t)s;
+                        break;
+                    }
+                    --r;
+                }
+            }
+        } while (k <= se);
+        return true;
+    }
+    // after the last scan: dequantise (16-bit products, as the reference's decoder) and transform every block
+    void prog_finish() {
+        for (int n = 0; n < ncomp; n++) {
+            Component &c = comp[n];
+            const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
+            for (int j = 0; j < bh; j++)
+                for (int i = 0; i < bw; i++) {
+                    int16_t *d = c.coef.data() + 64 * ((size_t)i + (size_t)j * c.blocks_w);
+                    for (int k = 0; k < 64; k++) d[k] = (int16_t)(d[k] * quant[c.tq][k]);
+                    idct_block(c.data.data() + (size_t)c.w2 * j * 8 + i * 8, c.w2, d);
+                }
+        }
+    }
+
     void restart() {
         bits.reset();
+        eob_run = 0;
         for (int i = 0; i < ncomp; i++) comp[i].dc_pred = 0;
     }
 
@@ -360,12 +480,25 @@ struct Decoder {
             comp[which].td = q >> 4;
             comp[which].ta = q & 15;
             if (comp[which].td > 3 || comp[which].ta > 3) return fail("bad SOS table id");
-            if (!dc[comp[which].td].present || !ac[comp[which].ta].present) return fail("missing huffman table");
             if (!have_quant[comp[which].tq]) return fail("missing quantisation table");
             order[i] = which;
         }
-        const int ss = u8(), se = u8(), a = u8();
-        if (ss != 0 || se != 63 || a != 0) return fail("bad SOS parameters");
+        ss = u8();
+        se = u8();
+        const int a = u8();
+        ah = a >> 4;
+        al = a & 15;
+        if (progressive) {
+            if (ss > 63 || se > 63 || ss > se || ah > 13 || al > 13) return fail("bad SOS parameters");
+            if (ss != 0 && ns != 1) return fail("interleaved AC scan");
+        } else if (ss != 0 || se != 63 || a != 0) {
+            return fail("bad SOS parameters");
+        }
+        for (int i = 0; i < ns; i++) {
+            const Component &c = comp[order[i]];
+            const bool need_dc = !progressive || (ss == 0 && ah == 0), need_ac = !progressive || ss != 0;
+            if ((need_dc && !dc[c.td].present) || (need_ac && !ac[c.ta].present)) return fail("missing huffman table");
+        }
         bits.p = p;
         bits.end = end;
         restart();
@@ -387,8 +520,13 @@ struct Decoder {
             const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
             for (int j = 0; j < bh && !stop; j++)
                 for (int i = 0; i < bw && !stop; i++) {
-                    if (!decode_block(c, d)) return false;
-                    idct_block(c.data.data() + (size_t)c.w2 * j * 8 + i * 8, c.w2, d);
+                    if (progressive) {
+                        int16_t *blk = c.coef.data() + 64 * ((size_t)i + (size_t)j * c.blocks_w);
+                        if (!(ss == 0 ? prog_dc(c, blk) : prog_ac(c, blk))) return false;
+                    } else {
+                        if (!decode_block(c, d)) return false;
+                        idct_block(c.data.data() + (size_t)c.w2 * j * 8 + i * 8, c.w2, d);
+                    }
                     if (!mcu_done()) stop = true;
                 }
         } else { // interleaved MCUs (T.81 A.2.3)
@@ -398,6 +536,11 @@ struct Decoder {
                         Component &c = comp[order[k]];
                         for (int y = 0; y < c.v; y++)
                             for (int x = 0; x < c.h; x++) {
+                                if (progressive) { // only DC scans are interleaved
+                                    int16_t *blk = c.coef.data() + 64 * ((size_t)(i * c.h + x) + (size_t)(j * c.v + y) * c.blocks_w);
+                                    if (!prog_dc(c, blk)) return false;
+                                    continue;
+                                }
                                 if (!decode_block(c, d)) return false;
                                 idct_block(c.data.data() + (size_t)c.w2 * ((j * c.v + y) * 8) + (i * c.h + x) * 8, c.w2, d);
                             }
@@ -444,9 +587,10 @@ struct Decoder {
             switch (m) {
             case 0xc0:
             case 0xc1:
+            case 0xc2:
+                progressive = m == 0xc2;
                 if (!read_sof(len)) return false;
                 break;
-            case 0xc2: return fail("progressive JPEG is not supported");
             case 0xc3: case 0xc5: case 0xc6: case 0xc7: case 0xc9: case 0xca: case 0xcb: case 0xcd: case 0xce: case 0xcf:
                 return fail("unsupported JPEG coding process");
             case 0xc4:
@@ -468,6 +612,7 @@ struct Decoder {
             p = seg_end;
         }
         if (!have_frame || !seen_scan) return fail("no image data");
+        if (progressive) prog_finish();
         img.width = width;
         img.height = height;
         img.file_components = ncomp;

@@ -17,7 +17,7 @@ reference's own code (scene graphs, hit records, rendered pixel sums); no refere
                  first_scene(animation=true) -> camera::render_animation() run, single-threaded from the process's
                  default rand() seed: camera frame and write_color ints of each of its 42 frames
   jpeg/*.jpg + jpeg_expected.npz  small JPEGs written with Pillow (4:4:4 / 4:2:2 / 4:2:0 / 4:1:1, grey, odd and
-                 one-pixel sizes, restart intervals, optimised tables, progressive) and the linearised RGB8 texels the
+                 one-pixel sizes, restart intervals, optimised tables, progressive scans) and the linearised RGB8 texels the
                  reference's rtw_image::load gives for each (--jpeg-only)
   anim_rotate.npz     camera frames of the 62-frame rotate + zoom sequence (camera.h:49-59,93-96; the reference's
                  rotate()/zoom()/initialize() driven in that order by refgen), 24x16
@@ -125,7 +125,13 @@ JPEG_CASES = [  # name, width, height, PIL save options  (mode L when "grey")
     ("c444_rst_rows", 50, 40, dict(quality=70, subsampling=0, restart_marker_rows=1)),
     ("grey_q80", 33, 19, dict(quality=80)),
     ("grey_rst", 40, 40, dict(quality=60, restart_marker_blocks=2)),
-    ("c420_progressive", 48, 32, dict(quality=75, subsampling=2, progressive=True)),  # not read by this decoder
+    ("c420_progressive", 48, 32, dict(quality=75, subsampling=2, progressive=True)),
+    ("c444_progressive", 37, 29, dict(quality=90, subsampling=0, progressive=True)),
+    ("c422_progressive_q20", 61, 18, dict(quality=20, subsampling=1, progressive=True)),
+    ("c420_progressive_rst", 72, 40, dict(quality=80, subsampling=2, progressive=True, restart_marker_blocks=2)),
+    ("c420_progressive_wide", 301, 24, dict(quality=95, subsampling=2, progressive=True, optimize=True)),
+    ("grey_progressive", 33, 19, dict(quality=80, progressive=True)),
+    ("c420_progressive_1x1", 1, 1, dict(quality=80, subsampling=2, progressive=True)),
 ]
 
 

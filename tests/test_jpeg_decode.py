@@ -3,7 +3,7 @@
 The expected texels (tests/golden/jpeg_expected.npz, raytracing_amd/assets/earthmap.jpg.rtwtex) were produced by the
 compiled reference's own rtw_image::load (stb_image_utils.h:46-55) on the same files -- tests/golden/make_golden.py
 --jpeg-only -- so equality here is equality with the reference's texture pipeline: Huffman decoding, the fixed-point
-inverse DCT, chroma upsampling, YCbCr -> RGB, gamma-2.2 linearisation, float -> byte.  Bar: bit-exact.  CPU only."""
+inverse DCT, progressive scans, chroma upsampling, YCbCr -> RGB, gamma-2.2 linearisation, float -> byte.  Bar: bit-exact.  CPU only."""
 import ctypes
 import os
 
@@ -15,7 +15,7 @@ from raytracing_amd import host
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 JPEG = os.path.join(ROOT, "tests", "golden", "jpeg")
 EXPECTED = np.load(os.path.join(ROOT, "tests", "golden", "jpeg_expected.npz"))
-CASES = sorted(n for n in EXPECTED.files if n != "c420_progressive")
+CASES = sorted(EXPECTED.files)
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -28,7 +28,8 @@ def test_decode_matches_reference_texels(name):
 
 def test_fixture_set_covers_the_sampling_modes():
     names = set(EXPECTED.files)
-    for need in ("c444_q90", "c422_q75", "c420_q75", "c411_q80", "grey_q80", "c420_rst", "c420_1x1", "c420_opt"):
+    for need in ("c444_q90", "c422_q75", "c420_q75", "c411_q80", "grey_q80", "c420_rst", "c420_1x1", "c420_opt",
+                 "c420_progressive", "c420_progressive_rst", "grey_progressive"):
         assert need in names
 
 
@@ -43,12 +44,24 @@ def test_earthmap_matches_reference_texels():
 
 
 def test_unsupported_and_broken_files_fail_loudly(tmp_path):
-    # progressive: the reference's decoder reads it, this one does not -- it must say so, not return garbage
+    data = bytearray(open(os.path.join(JPEG, "c420_q75.jpg"), "rb").read())
+    # the same file declared arithmetic-coded (SOF9) / lossless (SOF3): neither decoder reads those
+    sof = data.index(b"\xff\xc0")
+    for marker in (0xC9, 0xC3):
+        bad = tmp_path / f"sof_{marker:x}.jpg"
+        data[sof + 1] = marker
+        bad.write_bytes(bytes(data))
+        with pytest.raises(RuntimeError):
+            host.load_image(str(bad))
+    data[sof + 1] = 0xC0
+    data[sof + 4] = 12  # 12-bit samples
+    bad = tmp_path / "twelve_bit.jpg"
+    bad.write_bytes(bytes(data))
     with pytest.raises(RuntimeError):
-        host.load_image(os.path.join(JPEG, "c420_progressive.jpg"))
-    data = open(os.path.join(JPEG, "c420_q75.jpg"), "rb").read()
+        host.load_image(str(bad))
+    data[sof + 4] = 8
     bad = tmp_path / "truncated_header.jpg"
-    bad.write_bytes(data[:40])
+    bad.write_bytes(bytes(data[:40]))
     with pytest.raises(RuntimeError):
         host.load_image(str(bad))
     junk = tmp_path / "junk.jpg"
