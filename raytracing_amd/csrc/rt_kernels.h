@@ -1090,7 +1090,8 @@ enum : int { A_BOX = 0, A_SPHERE = 1, A_AABOX = 2, A_MEDIUM = 3, A_OTHER = 4, A_
 // need (64-lane divergence is the limiter of this workload: see DESIGN.md, profiles/).
 // per-wave item state (32 ints behind the wave's accumulators):
 // slot k: ws[4k .. 4k+3] = tile origin i0, j0, chunk, valid; then the dealing item's slot, first sample and unit count
-enum : int { WS_SLOT_I0 = 0, WS_SLOT_J0 = 1, WS_SLOT_CHUNK = 2, WS_SLOT_VALID = 3, WS_CUR_SLOT = 40, WS_CUR_S0 = 41, WS_N_UNITS = 42 };
+enum : int { WS_SLOT_I0 = 0, WS_SLOT_J0 = 1, WS_SLOT_CHUNK = 2, WS_SLOT_VALID = 3, WS_CUR_SLOT = 4 * RT_ITEM_SLOTS, WS_CUR_S0 = 4 * RT_ITEM_SLOTS + 1,
+              WS_N_UNITS = 4 * RT_ITEM_SLOTS + 2 };
 
 template <class R, bool ALL_LDS, bool TAB_LDS, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT<R> cam_arg, RenderArgs a_arg, float *__restrict__ out,
@@ -1136,7 +1137,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     constexpr int NS = LdsLayout<R>::item_slots;
     constexpr int TPX = LdsLayout<R>::tile_px, TSH = LdsLayout<R>::tile_shift; // pixels per item, log2 of it
     for (int k = lane; k < LdsLayout<R>::wave_acc; k += 64) acc[k] = R(0);
-    if (lane < 48) ws[lane] = 0;
+    for (int k = lane; k < LdsLayout<R>::state_ints; k += 64) ws[k] = 0;
     RayT<R> ray;
     V3<R> beta;
     Trav<R> tv;

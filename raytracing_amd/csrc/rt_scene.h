@@ -191,7 +191,7 @@ template <class R> struct SceneT { // device pointers; passed to kernels by valu
 
 // LDS map of a workgroup (all offsets are compile-time constants, so no register holds them):
 //   [0, stream_off)            per wave: item_slots accumulator slots (items in flight) x tile_px pixels x RGB, then the
-//                              wave's item state (48 ints)
+//                              wave's item state (4 ints per slot + 16)
 //   [stream_off, ...)          the leading lds_units units of the record stream, then (when they fit) the shading tables
 #ifndef RT_ITEM_SLOTS
 #define RT_ITEM_SLOTS 8
@@ -206,11 +206,12 @@ template <class R> struct LdsLayout {
     static constexpr int block = sizeof(R) == 4 ? RT_F32_BLOCK : 512; // f32: 16 waves/CU, <= 128 VGPRs; f64 (parity path): 8 waves
     static constexpr int waves = block / 64;
     static constexpr int item_slots = RT_ITEM_SLOTS;                           // items in flight per wave
-    static constexpr int tile_h = RT_TILE_H, tile_px = 8 * tile_h, tile_shift = tile_h == 8 ? 6 : 5;
+    static constexpr int tile_h = RT_TILE_H, tile_px = 8 * tile_h, tile_shift = tile_h == 8 ? 6 : tile_h == 4 ? 5 : 4;
     static constexpr int slot_acc = tile_px * 3;                               // accumulator scalars per slot
     static constexpr int wave_acc = item_slots * slot_acc;                     // accumulator scalars per wave
-    static constexpr int wave_stride = wave_acc * (int)sizeof(R) + 48 * 4;     // bytes per wave (+ 48 ints of item state)
-    static_assert((tile_h == 8 || tile_h == 4) && item_slots >= 2 && item_slots <= 8, "tile / slot geometry");
+    static constexpr int state_ints = 4 * item_slots + 16;                     // per slot: i0, j0, chunk, valid; then the current item
+    static constexpr int wave_stride = wave_acc * (int)sizeof(R) + state_ints * 4; // bytes per wave
+    static_assert((tile_h == 8 || tile_h == 4 || tile_h == 2) && item_slots >= 2 && item_slots <= 16, "tile / slot geometry");
     static constexpr int wave_off = 0;
     static constexpr int stream_off = wave_off + waves * wave_stride;
     static constexpr int total_bytes = sizeof(R) == 4 ? 160 * 1024 - 512 : 160 * 1024 - 512 - 16 * 1024;
