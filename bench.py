@@ -40,6 +40,22 @@ def cpu_baseline(scene, cores):
             "sample": f"final_scene {W}x{H}, {spp} spp, depth 50 ({W * H * spp} samples, {dt:.1f} s wall)"}
 
 
+def profiled_hbm_traffic():
+    """HBM bytes per render_kernel launch of this same command (N=1), from the committed rocprofv3 PMC passes
+    (tools/prof_round.sh: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs; both count KB, and FETCH_SIZE is doubled
+    on gfx950 as MI355X_MICROARCH.md prescribes).  None when the summary is missing."""
+    import ast
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_dealing_hbm_counters.txt")
+    try:
+        for line in open(path):
+            if "render_kernel" in line:
+                c = ast.literal_eval(line[line.index("{"):].strip())
+                return int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
+    except (OSError, ValueError, KeyError, SyntaxError):
+        pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +130,7 @@ def main():
         # dominant kernel = render_kernel<float>; per launch each rank traces (s1-s0)/n^2 of the frame
         rank_samples = W * H * (s1 - s0)
         achieved = rank_samples * fps_flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+        traffic, traffic_src = profiled_hbm_traffic() if world == 1 and (a.width, a.height, a.spp) == (1920, 1080, 1000) else (None, None)
         out = {
             "metric": "Msamples/s (node), final_scene 1080p @1000 spp", "value": round(samples / sec_per_frame / 1e6, 3),
             "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -123,7 +140,9 @@ def main():
             "config": {"workload": f"final_scene {W}x{H}, {a.spp} spp (-> {n * n} stratified samples), depth {a.depth}, "
                                    f"spp range split over {world} GPU(s) + RCCL reduce", "samples_per_frame": samples},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 5), "traffic": None,
+                         "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 5), "traffic": traffic,
+                         "traffic_note": (f"HBM bytes per launch from the committed PMC passes ({traffic_src}); not collected live"
+                                          if traffic else "HBM counters need their own profiler passes (profiles/)"),
                          "kernel": "render_kernel<float>", "kernel_ms": round(kern_ms, 3),
                          "flops_per_sample": round(fps_flops, 1),
                          "note": "non-MFMA FP32 vector roof (SURVEY 8d): the scene is cache-resident, HBM is not the bound"},
