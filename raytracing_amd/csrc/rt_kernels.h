@@ -1083,7 +1083,7 @@ struct RenderArgs {
 enum : int { A_BOX = 0, A_SPHERE = 1, A_AABOX = 2, A_MEDIUM = 3, A_OTHER = 4, A_SHADE = 5, A_COUNT = 6, A_DEAL = 7 };
 
 // Persistent megakernel.  A workgroup stages the scene stream into LDS once, then each of its waves pulls work items
-// (8x4 pixel tile x chunk of the stratified sample range) from a global cursor.  Inside an item every lane owns a pixel
+// (8x2 pixel tile x chunk of the stratified sample range) from a global cursor.  Inside an item every lane owns a pixel
 // and runs its samples back to back (path regeneration).  The wave is a three-state machine: at any time a lane is at
 // a BOX record, at a leaf record, or waiting to be shaded; each trip of the loop runs ONE of the three code blocks,
 // chosen wave-uniformly, so the hot BOX step is never serialised behind leaf or shading code that only a few lanes
@@ -1127,8 +1127,8 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     ShadeProf sp{};
     unsigned long long sp_tail = 0, prof_idle = 0, prof_ready = 0, prof_all = 0, prof_tail = 0;
 #endif
-    // Work: an item = (8 x 4 pixel tile, chunk of the sample range) = 32 x samples UNITS, unit u = sample s0 + u / 32 of the
-    // tile's pixel u % 32.  Lanes do not own pixels: a lane whose path has ended takes the next unit (wave-level dealing:
+    // Work: an item = (8 x 2 pixel tile, chunk of the sample range) = 16 x samples UNITS, unit u = sample s0 + u / 16 of the
+    // tile's pixel u % 16.  Lanes do not own pixels: a lane whose path has ended takes the next unit (wave-level dealing:
     // rank among the asking lanes + the wave's cursor), so a pixel with short paths never leaves its lane idle while a
     // neighbour grinds through long ones; when the item has no units left the wave fetches the next item and keeps
     // dealing while the old item's last paths finish (two items in flight: `cur` deals, `prev` drains).  The RNG is keyed
@@ -1304,11 +1304,19 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             const unsigned long long midle = lane_mask(kind0 == K_IDLE);
             if (midle && units_left >= 0) {
                 if (units_left == 0) {
-                // the current item has no units left: take the next accumulator slot (once the item that used it NS items
-                // ago has drained: store it first) and fetch an item into it
-                const int t = wsl(WS_CUR_SLOT) + 1 == NS ? 0 : wsl(WS_CUR_SLOT) + 1;
-                const bool t_valid = wsl(4 * t + WS_SLOT_VALID) != 0;
-                if (!(t_valid && lane_mask(kind0 != K_IDLE && (pp >> TSH) == t))) {
+                // the current item has no units left: take an accumulator slot none of whose paths is still in flight (the
+                // first one in ring order: a slot that waits for one long path does not hold up the others), store the item
+                // that used it and fetch a new item into it
+                unsigned free_slots = (1u << NS) - 1u;
+#pragma unroll
+                for (int k = 0; k < NS; k++)
+                    if (lane_mask(kind0 != K_IDLE && (pp >> TSH) == k)) free_slots &= ~(1u << k);
+                const int first = wsl(WS_CUR_SLOT) + 1; // 1 .. NS
+                const unsigned rot = ((free_slots >> first) | (free_slots << (NS - first))) & ((1u << NS) - 1u);
+                if (rot) {
+                    int t = first + __builtin_ctz(rot);
+                    t = t >= NS ? t - NS : t;
+                    const bool t_valid = wsl(4 * t + WS_SLOT_VALID) != 0;
                     if (t_valid) flush(t, wsl(4 * t + WS_SLOT_I0), wsl(4 * t + WS_SLOT_J0), wsl(4 * t + WS_SLOT_CHUNK));
                     int item = 0;
                     if (lane == 0) item = (int)atomicAdd(&counters[1], 1ull);

@@ -194,10 +194,10 @@ template <class R> struct SceneT { // device pointers; passed to kernels by valu
 //                              wave's item state (4 ints per slot + 16)
 //   [stream_off, ...)          the leading lds_units units of the record stream, then (when they fit) the shading tables
 #ifndef RT_ITEM_SLOTS
-#define RT_ITEM_SLOTS 8
+#define RT_ITEM_SLOTS 16
 #endif
-#ifndef RT_TILE_H // an item's pixel tile is 8 wide and RT_TILE_H (8 or 4) high
-#define RT_TILE_H 4
+#ifndef RT_TILE_H // an item's pixel tile is 8 wide and RT_TILE_H (8, 4 or 2) high
+#define RT_TILE_H 2
 #endif
 #ifndef RT_F32_BLOCK
 #define RT_F32_BLOCK 1024
