@@ -1088,7 +1088,7 @@ enum : int { A_BOX = 0, A_SPHERE = 1, A_AABOX = 2, A_MEDIUM = 3, A_OTHER = 4, A_
 // a BOX record, at a leaf record, or waiting to be shaded; each trip of the loop runs ONE of the three code blocks,
 // chosen wave-uniformly, so the hot BOX step is never serialised behind leaf or shading code that only a few lanes
 // need (64-lane divergence is the limiter of this workload: see DESIGN.md, profiles/).
-// per-wave item state (32 ints behind the wave's accumulators):
+// per-wave item state (LdsLayout::state_ints ints behind the wave's accumulators):
 // slot k: ws[4k .. 4k+3] = tile origin i0, j0, chunk, valid; then the dealing item's slot, first sample and unit count
 enum : int { WS_SLOT_I0 = 0, WS_SLOT_J0 = 1, WS_SLOT_CHUNK = 2, WS_SLOT_VALID = 3, WS_CUR_SLOT = 4 * RT_ITEM_SLOTS, WS_CUR_S0 = 4 * RT_ITEM_SLOTS + 1,
               WS_N_UNITS = 4 * RT_ITEM_SLOTS + 2 };
