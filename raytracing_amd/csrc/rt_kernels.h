@@ -279,7 +279,11 @@ RT_DEV bool box_hit(const UnitT<R> &u0, const UnitT<R> &u1, V3<R> o, V3<R> inv, 
         // +-inf; min / max drop NaNs, so that axis then always passes: conservative for a bounding box (leaves are exact).
         const rt_f2 tx = rt_f2{bx0, bx1} * inv.x + noi.x, ty = rt_f2{by0, by1} * inv.y + noi.y, tz = rt_f2{bz0, bz1} * inv.z + noi.z;
         R tn = m_max(m_max(m_min(tx.x, tx.y), m_min(ty.x, ty.y)), m_max(m_min(tz.x, tz.y), tmin));
-        R tf = m_min(m_min(m_max(tx.x, tx.y), m_max(ty.x, ty.y)), m_min(m_max(tz.x, tz.y), tmax));
+        // (tmax is the closest hit so far, a value the compiler cannot prove canonical: through fminf it would first be
+        // quieted by a v_max_f32 x, x; the instruction itself needs no such thing)
+        float far_z;
+        asm("v_min_f32 %0, %1, %2" : "=v"(far_z) : "v"(m_max(tz.x, tz.y)), "v"(tmax));
+        R tf = m_min(m_min(m_max(tx.x, tx.y), m_max(ty.x, ty.y)), far_z);
         return tf > tn;
     } else {
         {
