@@ -1201,13 +1201,12 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
 #endif
             if (action == A_BOX) {
                 // a few BOX steps in a row while enough lanes stay at BOX records (amortises the block selection)
-                // (a BOX header is the integer 0: kind 0, no payload; the header is re-read behind the join so that one
-                // compare per step serves both the next step's lane mask and the repeat decision)
+                // (a BOX header is the integer 0: kind 0, no payload; one compare per step serves both the next step's lane
+                // mask and the repeat decision)
                 bool at_box = is_box;
                 for (int rep = 0; rep < RT_BOX_REPEAT; rep++) {
                     if (at_box) trav_box_step(mem, tv, tmin);
                     int h = tv.hdr;
-                    asm volatile("" : "+v"(h));
                     at_box = h == make_hdr(K_BOX, 0);
                     if (popc64(lane_mask(at_box)) < RT_BOX_REPEAT_MIN) break;
                 }
@@ -1223,7 +1222,6 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         trav_goto(mem, tv, tv.i + 2);
                     }
                     int h = tv.hdr;
-                    asm volatile("" : "+v"(h));
                     at = at && (h & 15) == K_SPHERE;
                     if (popc64(lane_mask(at)) < RT_LEAF_REPEAT_MIN) break;
                 }
@@ -1236,7 +1234,6 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         trav_goto(mem, tv, tv.i + 2);
                     }
                     int h = tv.hdr;
-                    asm volatile("" : "+v"(h));
                     at = at && (h & 15) == K_AABOX;
                     if (popc64(lane_mask(at)) < RT_LEAF_REPEAT_MIN) break;
                 }
@@ -1258,7 +1255,6 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         trav_leaf_step(mem, sc, tv, ray, tmin, mxi);
                     }
                     int h = tv.hdr;
-                    asm volatile("" : "+v"(h));
                     at = at && (h & 15) >= K_QUAD && (h & 15) < K_IDLE;
                     if (popc64(lane_mask(at)) < RT_LEAF_REPEAT_MIN) break;
                 }
