@@ -33,6 +33,7 @@
 
 #include "../rt_amd.h"
 #include "jpeg_baseline.h"
+#include "png_decode.h"
 
 using std::make_shared;
 using std::shared_ptr;
@@ -266,9 +267,9 @@ class perlin { // tables only; noise()/turb() run on the GPU
 
 // rtw_image (stb_image_utils.h:18-110): linearised RGB8 texels.  The reference decodes the file with the vendored
 // stb_image (stbi_loadf: 8-bit samples -> linear float by pow(x/255, 2.2) -> byte by int(256 f)).  Here a JPEG is
-// decoded by rtamd/jpeg_baseline.h, which reproduces that decoder's integer arithmetic, and linearised the same way;
-// any other format (PNG ...) must be supplied pre-decoded by the same pipeline as "<name>.rtwtex" ("RTWTEX01", int32 w,
-// int32 h, w*h*3 bytes) next to where the image would be.  Search path as the reference's (RTW_IMAGES first).
+// decoded by rtamd/jpeg_baseline.h (which reproduces that decoder's integer arithmetic), a PNG by rtamd/png_decode.h,
+// and linearised the same way; any other format must be supplied pre-decoded by the same pipeline as "<name>.rtwtex"
+// ("RTWTEX01", int32 w, int32 h, w*h*3 bytes) next to where the image would be.  Search path as the reference's.
 class rtw_image {
   public:
     rtw_image() {}
@@ -284,16 +285,29 @@ class rtw_image {
         }
         std::cerr << "ERROR: Could not load image file '" << image_filename << "'.\n";
     }
-    bool load(const std::string &filename) { return load_jpeg(filename) || load_predecoded(filename + ".rtwtex"); }
-    bool load_jpeg(const std::string &filename) {
+    bool load(const std::string &filename) { return load_encoded(filename) || load_predecoded(filename + ".rtwtex"); }
+    bool load_encoded(const std::string &filename) {
         std::ifstream f(filename, std::ios::binary);
         if (!f.is_open()) return false;
         std::vector<unsigned char> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-        if (!rtamd::jpeg::is_jpeg(file.data(), file.size())) return false;
-        rtamd::jpeg::Image img;
+        std::vector<unsigned char> rgb;
         std::string why;
-        if (!rtamd::jpeg::decode(file.data(), file.size(), img, &why)) {
-            std::cerr << "ERROR: '" << filename << "': " << why << ".\n";
+        int w = 0, h = 0;
+        if (rtamd::jpeg::is_jpeg(file.data(), file.size())) {
+            rtamd::jpeg::Image img;
+            if (!rtamd::jpeg::decode(file.data(), file.size(), img, &why)) {
+                std::cerr << "ERROR: '" << filename << "': " << why << ".\n";
+                return false;
+            }
+            w = img.width, h = img.height, rgb = std::move(img.rgb);
+        } else if (rtamd::png::is_png(file.data(), file.size())) {
+            rtamd::png::Image img;
+            if (!rtamd::png::decode(file.data(), file.size(), img, &why)) {
+                std::cerr << "ERROR: '" << filename << "': " << why << ".\n";
+                return false;
+            }
+            w = img.width, h = img.height, rgb = std::move(img.rgb);
+        } else {
             return false;
         }
         // stb_image.h:1373 (ldr -> hdr, gamma 2.2, scale 1) then stb_image_utils.h:87-93 (float -> byte)
@@ -303,10 +317,10 @@ class rtw_image {
             const float value = (float)(std::pow(v / 255.0f, gamma) * scale);
             lin[v] = value <= 0.0 ? 0 : 1.0 <= value ? 255 : static_cast<unsigned char>(256.0 * value);
         }
-        for (auto &t : img.rgb) t = lin[t];
-        image_width = img.width;
-        image_height = img.height;
-        bdata = std::move(img.rgb);
+        for (auto &t : rgb) t = lin[t];
+        image_width = w;
+        image_height = h;
+        bdata = std::move(rgb);
         return true;
     }
     bool load_predecoded(const std::string &filename) {

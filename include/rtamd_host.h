@@ -32,7 +32,7 @@ int rtamd_host_scene_camera(const rtamd_host_scene *s, rt_camera *out);
  * with out == NULL), or a negative status if cap is too small.  Frames are independent: frame f -> GPU f mod G. */
 int rtamd_host_scene_animation(const rtamd_host_scene *s, int method, rt_camera *out, int cap);
 /* rtw_image::load (stb_image_utils.h:46-55) for one file: the linearised RGB8 texels an image_texture samples.  A JPEG
- * (baseline, extended sequential or progressive) is decoded by include/rtamd/jpeg_baseline.h, anything else is read from
+ * (baseline, extended sequential or progressive) is decoded by include/rtamd/jpeg_baseline.h, a PNG by include/rtamd/png_decode.h, anything else is read from
  * "<path>.rtwtex".  Writes width and height; copies width*height*3 bytes to out when out != NULL and cap is large
  * enough.  Returns RT_OK, RT_ERR_INVALID for a file that cannot be read or decoded or a buffer that is too small. */
 int rtamd_host_load_image(const char *path, int *width, int *height, unsigned char *out, size_t cap);

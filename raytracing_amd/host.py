@@ -81,7 +81,7 @@ def build_scene(scene: int, image_width: int, image_height: int, samples_per_pix
 
 def load_image(path: str) -> np.ndarray:
     """rtw_image::load (stb_image_utils.h:46-55) for one file: (height, width, 3) linearised RGB8 texels.  JPEGs are
-    decoded by include/rtamd/jpeg_baseline.h; other formats are read from "<path>.rtwtex".  Raises RuntimeError for a
+    decoded by include/rtamd/jpeg_baseline.h, PNGs by include/rtamd/png_decode.h; other formats are read from "<path>.rtwtex".  Raises RuntimeError for a
     file that is missing, unsupported (progressive JPEG ...) or corrupt."""
     L = load()
     w, h = C.c_int(0), C.c_int(0)

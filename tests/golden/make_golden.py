@@ -19,6 +19,8 @@ reference's own code (scene graphs, hit records, rendered pixel sums); no refere
   jpeg/*.jpg + jpeg_expected.npz  small JPEGs written with Pillow (4:4:4 / 4:2:2 / 4:2:0 / 4:1:1, grey, odd and
                  one-pixel sizes, restart intervals, optimised tables, progressive scans) and the linearised RGB8 texels the
                  reference's rtw_image::load gives for each (--jpeg-only)
+  png/*.png + png_expected.npz  PNG files (Pillow-written and hand-assembled: every row filter, Adam7, 1/2/4/8-bit grey
+                 and palette, alpha, stored / fixed / dynamic deflate blocks) and their linearised RGB8 texels (--png-only)
   anim_rotate.npz     camera frames of the 62-frame rotate + zoom sequence (camera.h:49-59,93-96; the reference's
                  rotate()/zoom()/initialize() driven in that order by refgen), 24x16
 """
@@ -164,17 +166,136 @@ def make_jpeg():
     print("jpeg fixtures:", ", ".join(expected))
 
 
+def write_png(path, arr, color, depth=8, interlace=False, filters=(0, 1, 2, 3, 4), palette=None, level=6):
+    """Minimal PNG writer for the cases Pillow does not produce: chosen row filters, Adam7 interlace.  arr: (h, w) or
+    (h, w, c) uint8 samples (for depth < 8: one sample per pixel, values < 2**depth)."""
+    import struct
+    import zlib
+    arr = np.asarray(arr, np.uint8)
+    h, w = arr.shape[:2]
+    comps = 1 if arr.ndim == 2 else arr.shape[2]
+
+    def pack_rows(a):
+        rows = a.reshape(a.shape[0], -1)
+        if depth == 8:
+            return rows
+        per = 8 // depth
+        pad = (-rows.shape[1]) % per
+        rows = np.pad(rows, ((0, 0), (0, pad)))
+        out = np.zeros((rows.shape[0], rows.shape[1] // per), np.uint8)
+        for k in range(per):
+            out |= rows[:, k::per] << (8 - depth * (k + 1))
+        return out
+
+    def filt(rows):
+        bpp = max(1, comps * depth // 8)
+        out = bytearray()
+        prev = np.zeros(rows.shape[1], np.int32)
+        for y, r in enumerate(rows.astype(np.int32)):
+            f = filters[y % len(filters)]
+            a_ = np.concatenate([np.zeros(bpp, np.int32), r[:-bpp]]) if r.size > bpp else np.zeros_like(r)
+            c_ = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]]) if r.size > bpp else np.zeros_like(r)
+            if f == 0:
+                e = r
+            elif f == 1:
+                e = r - a_
+            elif f == 2:
+                e = r - prev
+            elif f == 3:
+                e = r - ((a_ + prev) >> 1)
+            else:
+                pq = a_ + prev - c_
+                pa, pb, pc = abs(pq - a_), abs(pq - prev), abs(pq - c_)
+                e = r - np.where((pa <= pb) & (pa <= pc), a_, np.where(pb <= pc, prev, c_))
+            out += bytes([f]) + (e & 255).astype(np.uint8).tobytes()
+            prev = r
+        return bytes(out)
+
+    if interlace:
+        xo, yo, xs, ys = (0, 4, 0, 2, 0, 1, 0), (0, 0, 4, 0, 2, 0, 1), (8, 8, 4, 4, 2, 2, 1), (8, 8, 8, 4, 4, 2, 2)
+        data = b"".join(filt(pack_rows(arr[yo[k]::ys[k], xo[k]::xs[k]])) for k in range(7)
+                        if arr[yo[k]::ys[k], xo[k]::xs[k]].size)
+    else:
+        data = filt(pack_rows(arr))
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color, 0, 0, int(interlace)))
+    if palette is not None:
+        out += chunk(b"PLTE", np.asarray(palette, np.uint8).tobytes())
+    co = zlib.compressobj(level)
+    z = co.compress(data) + co.flush()
+    out += chunk(b"IDAT", z[: len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:]) + chunk(b"tEXt", b"k\0v") + chunk(b"IEND", b"")
+    open(path, "wb").write(out)
+
+
+def make_png():
+    """tests/golden/png/*.png and png_expected.npz.  8-bit files: expected texels from the reference's rtw_image::load
+    (stb_image v2.06), cross-checked against Pillow's decode.  1/2/4-bit files: that stb version unfilters them against a
+    wrong prior row (it reads unwritten memory), so the expected texels are Pillow's decode put through the reference's
+    linearisation -- recorded as such in the archive ("spec_" prefix)."""
+    from PIL import Image
+    d = os.path.join(GOLD, "png")
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(77)
+    lin = np.array([0 if v == 0 else min(255, int(256.0 * float(np.float32(np.float32(v) / np.float32(255.0)) ** np.float32(2.2)))) for v in range(256)], np.uint8)
+    rgb = test_picture(37, 21, 5)
+    big = test_picture(300, 64, 6)
+    pal = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    cases = {
+        "rgb8": lambda p: Image.fromarray(rgb).save(p),
+        "rgba8": lambda p: Image.fromarray(np.dstack([rgb, rng.integers(0, 256, rgb.shape[:2], dtype=np.uint8)]), "RGBA").save(p),
+        "grey8": lambda p: Image.fromarray(rgb[..., 1]).save(p),
+        "greyalpha8": lambda p: Image.fromarray(np.dstack([rgb[..., 1], rgb[..., 2]]), "LA").save(p),
+        "pal8": lambda p: Image.fromarray(rgb).quantize(200).save(p),
+        "pal8_trns": lambda p: Image.fromarray(rgb).quantize(40).save(p, transparency=3),
+        "rgb8_big_l9": lambda p: Image.fromarray(big).save(p, compress_level=9),
+        "rgb8_stored": lambda p: Image.fromarray(rgb).save(p, compress_level=0),
+        "rgb8_filters": lambda p: write_png(p, big, 2),
+        "rgb8_adam7": lambda p: write_png(p, rgb, 2, interlace=True),
+        "rgba8_adam7_small": lambda p: write_png(p, np.dstack([rgb, rgb[..., 0]])[:5, :3], 6, interlace=True),
+        "grey8_fixed_huffman": lambda p: write_png(p, rgb[:4, :9, 0], 0, level=1),
+        "rgb8_1x1": lambda p: write_png(p, rgb[:1, :1], 2),
+        "spec_grey1": lambda p: write_png(p, (rgb[..., 0] > 128).astype(np.uint8), 0, depth=1),
+        "spec_grey2_adam7": lambda p: write_png(p, rgb[..., 0] >> 6, 0, depth=2, interlace=True),
+        "spec_grey4": lambda p: write_png(p, rgb[..., 0] >> 4, 0, depth=4),
+        "spec_pal4": lambda p: write_png(p, rgb[..., 1] >> 4, 3, depth=4, palette=pal),
+        "spec_pal1": lambda p: write_png(p, rgb[..., 1] >> 7, 3, depth=1, palette=pal[:2], filters=(0,)),
+    }
+    expected = {}
+    for name, make in cases.items():
+        path = os.path.join(d, name + ".png")
+        make(path)
+        spec = lin[np.asarray(Image.open(path).convert("RGB"))]
+        if name.startswith("spec_"):
+            expected[name] = spec
+            continue
+        out = f"{OUT}/{name}.rtwtex"
+        refgen("teximg", path, out)
+        b = open(out, "rb").read()
+        tw, th = (int(v) for v in np.frombuffer(b, "<i4", 2, 8))
+        ref = np.frombuffer(b, np.uint8, tw * th * 3, 16).reshape(th, tw, 3).copy()
+        assert np.array_equal(ref, spec), name  # the reference's decoder and Pillow agree on 8-bit files
+        expected[name] = ref
+    np.savez_compressed(f"{GOLD}/png_expected.npz", **expected)
+    print("png fixtures:", ", ".join(expected))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--converged", action="store_true", help="also (re)run the long converged renders")
     ap.add_argument("--scenes", default="1,2,3,4")
     ap.add_argument("--anim-only", action="store_true", help="only (re)generate the animation fixtures")
     ap.add_argument("--jpeg-only", action="store_true", help="only (re)generate the JPEG decoding fixtures")
+    ap.add_argument("--png-only", action="store_true", help="only (re)generate the PNG decoding fixtures")
     a = ap.parse_args()
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
     os.makedirs(OUT, exist_ok=True)
     if a.jpeg_only:
         make_jpeg()
+        return
+    if a.png_only:
+        make_png()
         return
     make_anim()
     if a.anim_only:
