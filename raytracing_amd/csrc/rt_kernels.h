@@ -1089,11 +1089,11 @@ struct RenderArgs {
 enum : int { A_BOX = 0, A_SPHERE = 1, A_AABOX = 2, A_MEDIUM = 3, A_OTHER = 4, A_SHADE = 5, A_COUNT = 6, A_DEAL = 7 };
 
 // Persistent megakernel.  A workgroup stages the scene stream into LDS once, then each of its waves pulls work items
-// (8x2 pixel tile x chunk of the stratified sample range) from a global cursor.  Inside an item every lane owns a pixel
-// and runs its samples back to back (path regeneration).  The wave is a three-state machine: at any time a lane is at
-// a BOX record, at a leaf record, or waiting to be shaded; each trip of the loop runs ONE of the three code blocks,
-// chosen wave-uniformly, so the hot BOX step is never serialised behind leaf or shading code that only a few lanes
-// need (64-lane divergence is the limiter of this workload: see DESIGN.md, profiles/).
+// (8x2 pixel tile x chunk of the stratified sample range) from a global cursor and deals the item's (pixel, sample)
+// units to whichever lanes are free.  The wave is a state machine: at any time a lane is at a BOX / SPHERE / AABOX /
+// MEDIUM / other record, waiting to be shaded, or idle; each trip of the loop runs ONE code block, chosen
+// wave-uniformly, so the hot BOX step is never serialised behind leaf or shading code that only a few lanes need
+// (64-lane divergence is the limiter of this workload: see DESIGN.md, profiles/).
 // per-wave item state (LdsLayout::state_ints ints behind the wave's accumulators):
 // slot k: ws[4k .. 4k+3] = tile origin i0, j0, chunk, valid; then the dealing item's slot, first sample and unit count
 enum : int { WS_SLOT_I0 = 0, WS_SLOT_J0 = 1, WS_SLOT_CHUNK = 2, WS_SLOT_VALID = 3, WS_CUR_SLOT = 4 * RT_ITEM_SLOTS, WS_CUR_S0 = 4 * RT_ITEM_SLOTS + 1,
@@ -1137,9 +1137,10 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     // tile's pixel u % 16.  Lanes do not own pixels: a lane whose path has ended takes the next unit (wave-level dealing:
     // rank among the asking lanes + the wave's cursor), so a pixel with short paths never leaves its lane idle while a
     // neighbour grinds through long ones; when the item has no units left the wave fetches the next item and keeps
-    // dealing while the old item's last paths finish (two items in flight: `cur` deals, `prev` drains).  The RNG is keyed
-    // by (pixel, sample), so the image does not depend on who traces what; a finished path is added to its item's
-    // per-pixel accumulator in LDS (ds_add: the order of the adds is this wave's own deterministic schedule).
+    // dealing while the old items' last paths finish (NS items in flight, one accumulator slot each).  The RNG is keyed
+    // by (pixel, sample), so the paths do not depend on who traces what; a finished path is added to its item's
+    // per-pixel accumulator in LDS (ds_add: the order of the adds follows this wave's schedule, so float sums repeat
+    // from run to run only to rounding once a wave handles several items).
     constexpr int NS = LdsLayout<R>::item_slots;
     constexpr int TPX = LdsLayout<R>::tile_px, TSH = LdsLayout<R>::tile_shift; // pixels per item, log2 of it
     for (int k = lane; k < LdsLayout<R>::wave_acc; k += 64) acc[k] = R(0);
