@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RT_AMD_ABI_VERSION 1
+#define RT_AMD_ABI_VERSION 2 /* 2: rt_render_params.s_end < 0 (not <= 0) means "all strata"; rt_render_multi */
 
 /* ---- status codes ---------------------------------------------------------------------------- */
 enum {
@@ -178,10 +178,12 @@ enum rt_precision {
     RT_PREC_F64 = 1  /* reference arithmetic (double, no FMA contraction): the parity path */
 };
 
+#define RT_ALL_STRATA (-1)
 typedef struct rt_render_params {
     uint64_t seed;      /* counter-based RNG seed; results depend on (seed,pixel,sample) only   */
     int32_t s_begin;    /* linear stratum index range [s_begin,s_end) of sqrt_spp^2 samples:     */
-    int32_t s_end;      /*   s = s_j*sqrt_spp + s_i (camera.h:176-181); s_end<=0 means all       */
+    int32_t s_end;      /*   s = s_j*sqrt_spp + s_i (camera.h:176-181); s_end < 0 (RT_ALL_STRATA) means  */
+                        /*   sqrt_spp^2; s_begin == s_end is an EMPTY range (a rank with no strata)  */
     int32_t precision;  /* rt_precision */
     int32_t sample_chunks; /* 0 = auto; >0 forces the number of sample chunks per pixel tile     */
 } rt_render_params;
@@ -224,7 +226,8 @@ int rt_abi_sizeof(const char *name);
  * (cpuRenderer.cpp:86-401 build it; bvh_node ctor bvh.h:15-41 is run by the host API before this). */
 int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out);
 void rt_scene_free(rt_scene *scene);
-/* out[4] = { threaded device nodes, lights, f32 device bytes, f64 device bytes }. */
+/* out[4] = { threaded device nodes, lights, f32 device bytes, f64 device bytes (0 until a call first asks for
+ * RT_PREC_F64: the parity stream is built lazily) }. */
 int rt_scene_info(const rt_scene *scene, int32_t *out);
 
 /* Host-only (no GPU, no context): run the flattener on `desc` and report what rt_scene_upload would put on the device:
@@ -259,6 +262,16 @@ int rt_tonemap_device(rt_ctx *ctx, const float *d_accum, double scale, size_t n_
  * rgb8 (optional) the write_color bytes scaled by 1/sqrt_spp^2. */
 int rt_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_params *params,
               float *accum_rgb, uint8_t *rgb8, rt_stats *stats);
+
+/* One frame on SEVERAL GPUs from one process (what `rtamd_render --gpus N` and camera::render under RTAMD_DEVICES use;
+ * one-process-per-GPU callers use rt_render_device + an RCCL reduce instead).  ctxs[k] / scenes[k]: one context per device
+ * and the same scene uploaded through each (two contexts may share a device).  Context k traces strata
+ * [s_begin + k*n/G, s_begin + (k+1)*n/G) of the n = s_end - s_begin requested -- the RNG is keyed by (seed, pixel, stratum),
+ * so the image does not depend on G (the reference has no multi-GPU code) -- all devices run side by side, then
+ * the peers' float sums are copied to ctxs[0]'s device and added in context order.  Outputs as rt_render; stats->kernel_ms
+ * is the slowest device's.  Errors of any context are reported through rt_last_error(ctxs[0]). */
+int rt_render_multi(rt_ctx *const *ctxs, const rt_scene *const *scenes, int n_devices, const rt_camera *cam,
+                    const rt_render_params *params, float *accum_rgb, uint8_t *rgb8, rt_stats *stats);
 
 #ifdef __cplusplus
 }

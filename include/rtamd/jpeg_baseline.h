@@ -312,6 +312,9 @@ struct Decoder {
             if (c.h > h_max) h_max = c.h;
             if (c.v > v_max) v_max = c.v;
         }
+        // the upsampler handles whole ratios only (1, 2, 3 = h_max / c.h, 4): a 3:2 frame would be read past its rows
+        for (int i = 0; i < ncomp; i++)
+            if (h_max % comp[i].h != 0 || v_max % comp[i].v != 0) return fail("non-integer chroma sampling ratio");
         if ((int64_t)width * height > (int64_t)1 << 28) return fail("image too large");
         mcus_x = (width + 8 * h_max - 1) / (8 * h_max);
         mcus_y = (height + 8 * v_max - 1) / (8 * v_max);

@@ -8,6 +8,7 @@
 // by the compiled reference (tests/test_png_decode.py).  Header-only, host code.
 #ifndef RTAMD_PNG_DECODE_H
 #define RTAMD_PNG_DECODE_H
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -283,7 +284,7 @@ struct Decoder {
                 if (pw && ph) want += (size_t)ph * (row_bytes(pw) + 1);
             }
         std::vector<uint8_t> raw;
-        raw.reserve(want);
+        raw.reserve(std::min(want, (size_t)1 << 24)); // a header may claim any size: grow with the data that actually inflates
         if (!zlib_inflate(z, raw, want + 64) || raw.size() < want) return fail("corrupt compressed data");
 
         img.width = (int)w;

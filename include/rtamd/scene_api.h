@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -941,7 +942,9 @@ struct Image {
     int *data;
 };
 
-inline void writePPMImage(const Image *image, const char *filename) { // color.h:72: ASCII P3
+// color.h:72: ASCII P3, byte for byte what the reference's fprintf("%d %d %d\n") loop writes -- formatted into one
+// buffer and written with a single fwrite (a 1080p frame is 6.2 M numbers: 1.3 s through fprintf, 25 ms this way).
+inline void writePPMImage(const Image *image, const char *filename) {
     FILE *fp = fopen(filename, "wb");
     if (!fp) {
         fprintf(stderr, "Error: could not open %s for write\n", filename);
@@ -950,25 +953,79 @@ inline void writePPMImage(const Image *image, const char *filename) { // color.h
     fprintf(fp, "P3\n");
     fprintf(fp, "%d %d\n", image->width, image->height);
     fprintf(fp, "255\n");
-    for (int j = 0; j < image->height; j++)
-        for (int i = 0; i < image->width; i++) {
-            const int *ptr = &image->data[3 * (j * image->width + i)];
-            fprintf(fp, "%d %d %d\n", ptr[0], ptr[1], ptr[2]);
+    const size_t n = (size_t)image->width * image->height;
+    std::vector<char> buf(n * 36 + 1); // an int takes at most 11 characters
+    char *o = buf.data();
+    auto put = [&](int v, char sep) {
+        if (v >= 0 && v < 1000) {
+            if (v >= 100) *o++ = char('0' + v / 100);
+            if (v >= 10) *o++ = char('0' + (v / 10) % 10);
+            *o++ = char('0' + v % 10);
+        } else {
+            o += snprintf(o, 12, "%d", v);
         }
+        *o++ = sep;
+    };
+    for (size_t k = 0; k < n; k++) {
+        const int *ptr = &image->data[3 * k];
+        put(ptr[0], ' ');
+        put(ptr[1], ' ');
+        put(ptr[2], '\n');
+    }
+    fwrite(buf.data(), 1, (size_t)(o - buf.data()), fp);
     fclose(fp);
 }
 
 // ---- camera.h -----------------------------------------------------------------------------------------------------------
 namespace rtamd {
-// One lazily created GPU context per process for the scene API (device = $RTAMD_DEVICE or 0).
-inline rt_ctx *session() {
-    static rt_ctx *ctx = nullptr;
-    if (!ctx) {
-        const char *dev = getenv("RTAMD_DEVICE");
-        int rc = rt_init(dev ? atoi(dev) : 0, &ctx);
-        if (rc != RT_OK) throw std::runtime_error("rtamd: rt_init failed (status " + std::to_string(rc) + "): no usable MI355X/HIP device");
+// The GPU contexts of this process, created on first use: one per entry of $RTAMD_DEVICES ("0,1,2,3": a frame's strata are
+// split over them by rt_render_multi; an index may repeat), else the single device $RTAMD_DEVICE (default 0).
+inline std::vector<rt_ctx *> &sessions() {
+    static std::vector<rt_ctx *> ctxs;
+    if (ctxs.empty()) {
+        std::vector<int> devs;
+        if (const char *list = getenv("RTAMD_DEVICES")) {
+            std::stringstream ss(list);
+            std::string tok;
+            while (std::getline(ss, tok, ','))
+                if (!tok.empty()) devs.push_back(atoi(tok.c_str()));
+        }
+        if (devs.empty()) {
+            const char *dev = getenv("RTAMD_DEVICE");
+            devs.push_back(dev ? atoi(dev) : 0);
+        }
+        for (int d : devs) {
+            rt_ctx *c = nullptr;
+            int rc = rt_init(d, &c);
+            if (rc != RT_OK) {
+                for (rt_ctx *x : ctxs) rt_shutdown(x);
+                ctxs.clear();
+                throw std::runtime_error("rtamd: rt_init(" + std::to_string(d) + ") failed (status " + std::to_string(rc) + "): no usable MI355X/HIP device");
+            }
+            ctxs.push_back(c);
+        }
     }
-    return ctx;
+    return ctxs;
+}
+inline rt_ctx *session() { return sessions()[0]; }
+
+// A flattened scene uploaded to every context of sessions(); freed with the object.
+struct UploadedScene {
+    std::vector<rt_scene *> scenes;
+    double flatten_ms = 0, upload_ms = 0;
+    UploadedScene() = default;
+    UploadedScene(const UploadedScene &) = delete;
+    UploadedScene &operator=(const UploadedScene &) = delete;
+    ~UploadedScene() {
+        for (rt_scene *s : scenes) rt_scene_free(s);
+    }
+};
+// Wall-clock pieces of the last camera::render / render_animation frame (milliseconds).
+struct FrameTiming {
+    double flatten_ms = 0, upload_ms = 0, render_ms = 0 /* kernels + reduce + D2H, host-side wall clock */, write_ms = 0;
+};
+inline double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 } // namespace rtamd
 
@@ -998,14 +1055,17 @@ class camera {
     // extensions (not in the reference): RNG seed, and statistics of the last render
     uint64_t seed = 1984;
     rt_stats last_stats{};
+    rtamd::FrameTiming last_timing{};
     bool write_file = true;
 
     // camera.h:157: one still frame to ./images/<filename>
     void render(const hittable &world, const hittable &lights) {
         initialize();
         snprintf(filepath, sizeof(filepath), "./images/%s", filename.c_str());
-        render_frame(world, lights);
-        if (write_file) writePPMImage(image, filepath);
+        rtamd::UploadedScene up;
+        upload(world, lights, up);
+        render_frame(up);
+        write_frame();
     }
 
     // camera.h:46.  The reference tests `if (animation_method = 0) ... else if (animation_method = 1)` (assignments), so
@@ -1013,11 +1073,13 @@ class camera {
     // zoom sequence that code was written to run (camera.h:48-97), method 1 the translate sequence (98-153).
     void render_animation(const hittable &world, const hittable &lights) {
         const int n = animation_frames();
+        rtamd::UploadedScene up; // the world does not change between frames: flattened and uploaded once, only the camera moves
+        upload(world, lights, up);
         for (int frame = 0; frame < n; frame++) {
             animation_step(frame);
             snprintf(filepath, sizeof(filepath), "./images/animation/image%d.ppm", frame);
-            render_frame(world, lights);
-            if (write_file) writePPMImage(image, filepath);
+            render_frame(up);
+            write_frame();
         }
     }
 
@@ -1116,22 +1178,44 @@ class camera {
     double anim_theta_ = 0, anim_phi_ = 0;
     std::shared_ptr<Image> image_owner_; // `image` points into it; copies of a camera share the buffer until re-initialised
 
-    void render_frame(const hittable &world, const hittable &lights) {
+    // flatten world / lights and upload the result to every context of the process
+    void upload(const hittable &world, const hittable &lights, rtamd::UploadedScene &up) {
+        const double t0 = rtamd::now_ms();
         rtamd::FlatScene f;
         flatten(world, lights, f);
         rt_scene_desc d = f.desc();
-        rt_ctx *ctx = rtamd::session();
-        rt_scene *scene = nullptr;
-        int rc = rt_scene_upload(ctx, &d, &scene);
-        if (rc != RT_OK) throw std::runtime_error(std::string("rtamd: rt_scene_upload: ") + rt_last_error(ctx));
+        const double t1 = rtamd::now_ms();
+        for (rt_ctx *ctx : rtamd::sessions()) {
+            rt_scene *scene = nullptr;
+            int rc = rt_scene_upload(ctx, &d, &scene);
+            if (rc != RT_OK) throw std::runtime_error(std::string("rtamd: rt_scene_upload: ") + rt_last_error(ctx));
+            up.scenes.push_back(scene);
+        }
+        up.flatten_ms = t1 - t0;
+        up.upload_ms = rtamd::now_ms() - t1;
+    }
+    // one frame of the current camera on the GPU(s) -> image->data
+    void render_frame(const rtamd::UploadedScene &up) {
+        const double t0 = rtamd::now_ms();
         std::vector<uint8_t> rgb((size_t)image_width * image_height * 3);
         rt_render_params p{};
         p.seed = seed;
+        p.s_end = RT_ALL_STRATA;
         p.precision = RT_PREC_F32;
-        rc = rt_render(ctx, scene, &frame_, &p, nullptr, rgb.data(), &last_stats);
-        rt_scene_free(scene);
-        if (rc != RT_OK) throw std::runtime_error(std::string("rtamd: rt_render: ") + rt_last_error(ctx));
+        std::vector<rt_ctx *> &ctxs = rtamd::sessions();
+        int rc;
+        if (ctxs.size() == 1) rc = rt_render(ctxs[0], up.scenes[0], &frame_, &p, nullptr, rgb.data(), &last_stats);
+        else rc = rt_render_multi(ctxs.data(), up.scenes.data(), (int)ctxs.size(), &frame_, &p, nullptr, rgb.data(), &last_stats);
+        if (rc != RT_OK) throw std::runtime_error(std::string("rtamd: rt_render: ") + rt_last_error(ctxs[0]));
         for (size_t k = 0; k < rgb.size(); k++) image->data[k] = rgb[k];
+        last_timing.flatten_ms = up.flatten_ms;
+        last_timing.upload_ms = up.upload_ms;
+        last_timing.render_ms = rtamd::now_ms() - t0;
+    }
+    void write_frame() {
+        const double t0 = rtamd::now_ms();
+        if (write_file) writePPMImage(image, filepath);
+        last_timing.write_ms = rtamd::now_ms() - t0;
     }
 
     void rotate(double theta, double phi) { // camera.h:328

@@ -718,7 +718,7 @@ int orc_trace_batch(const rt_scene_desc *sc, const rt_ray *rays, const double *x
 int orc_render(const rt_scene_desc *sc, const rt_camera *cam, uint64_t seed, int s_begin, int s_end, int rng_mode,
                int num_threads, double *accum, uint64_t *counters /* optional [6]: aabb,sphere,quad,tri,rays,samples */) {
     const int W = cam->image_width, H = cam->image_height, n = cam->sqrt_spp;
-    if (s_end <= 0) s_end = n * n;
+    if (s_end < 0) s_end = n * n; // RT_ALL_STRATA; s_begin == s_end is an empty range
     Cam cm{cam, 1.0 / n};
     uint64_t tot[6] = {0, 0, 0, 0, 0, 0};
     if (rng_mode == RNG_GLIBC) num_threads = 1;

@@ -21,8 +21,10 @@ struct rt_ctx {
     std::string err;
     float *partial = nullptr; // per-chunk accumulation buffers [n_chunks][H][W][3]
     size_t partial_bytes = 0;
-    float *accum = nullptr; // used by the host-buffer convenience entry point rt_render
+    float *accum = nullptr; // used by the host-buffer convenience entry points rt_render / rt_render_multi
     size_t accum_bytes = 0;
+    float *stage = nullptr; // rt_render_multi: where the root device receives a peer's buffer
+    size_t stage_bytes = 0;
     uint8_t *rgb = nullptr;
     size_t rgb_bytes = 0;
     unsigned long long *counter = nullptr;
@@ -40,10 +42,45 @@ template <class R> struct DeviceScene {
     int n_fused_boxes = 0;
 };
 
+// A private copy of the caller's description: the caller owns (and may free) the arrays it passed to rt_scene_upload, and
+// the f64 parity stream is only built when a call first asks for RT_PREC_F64.
+struct DescCopy {
+    rt_scene_desc d{};
+    std::vector<rt_node> nodes;
+    std::vector<int32_t> child_index;
+    std::vector<rt_sphere> spheres;
+    std::vector<rt_quad> quads;
+    std::vector<rt_triangle> triangles;
+    std::vector<rt_material> materials;
+    std::vector<rt_texture> textures;
+    std::vector<rt_image> images;
+    std::vector<uint8_t> image_bytes;
+    std::vector<rt_perlin> perlins;
+    void assign(const rt_scene_desc &src) {
+        d = src;
+        auto cp = [](auto &v, const auto *p, int64_t n) {
+            v.assign(p, p + (n > 0 && p ? n : 0));
+            return v.empty() ? nullptr : v.data();
+        };
+        d.nodes = cp(nodes, src.nodes, src.n_nodes);
+        d.child_index = cp(child_index, src.child_index, src.n_child_index);
+        d.spheres = cp(spheres, src.spheres, src.n_spheres);
+        d.quads = cp(quads, src.quads, src.n_quads);
+        d.triangles = cp(triangles, src.triangles, src.n_triangles);
+        d.materials = cp(materials, src.materials, src.n_materials);
+        d.textures = cp(textures, src.textures, src.n_textures);
+        d.images = cp(images, src.images, src.n_images);
+        d.image_bytes = cp(image_bytes, src.image_bytes, src.n_image_bytes);
+        d.perlins = cp(perlins, src.perlins, src.n_perlins);
+    }
+};
+
 struct rt_scene {
     rt_ctx *ctx = nullptr;
     DeviceScene<float> f32;
-    DeviceScene<double> f64;
+    DeviceScene<double> f64; // built on first use (RT_PREC_F64 is the parity path, never the production one)
+    bool have_f64 = false;
+    DescCopy desc;
     int n_nodes_desc = 0;
 };
 
@@ -149,6 +186,144 @@ int ensure(rt_ctx *ctx, void **p, size_t *have, size_t want) {
     return RT_OK;
 }
 
+// The f64 (parity) stream of a scene, built and uploaded the first time a call asks for RT_PREC_F64.
+int need_f64(rt_ctx *ctx, const rt_scene *scene_) {
+    rt_scene *scene = const_cast<rt_scene *>(scene_);
+    if (scene->have_f64) return RT_OK;
+    int rc = upload_one<double>(ctx, &scene->desc.d, scene->f64);
+    if (rc == RT_OK) scene->have_f64 = true;
+    return rc;
+}
+
+// What one render launch does, worked out on the host before anything is enqueued.
+struct RenderPlan {
+    RenderLaunch rl{};
+    int n_chunks = 0;
+    int n_samples = 0;
+    size_t n_px = 0;
+};
+
+// Argument checks + work decomposition.  A work item = (8 x RT_TILE_H pixel tile, chunk of the sample range); waves pull items
+// from a cursor in chunk-major order.  Default: a DECREASING-size schedule (each chunk takes a half / a third of what is left,
+// down to a minimum), so the bulk of the samples runs in long items (lanes regenerate paths inside an item; a short item
+// wastes lanes while its last paths finish) and the kernel ends on short ones (the end-of-kernel imbalance is one short item
+// per wave).  params->sample_chunks > 0 forces that many equal chunks instead.  max_chunks caps the number of chunks (the
+// partial frames must fit where the caller keeps them).
+int plan_render(rt_ctx *ctx, const rt_camera *cam, const rt_render_params *params, int max_chunks, RenderPlan &pl) {
+    if (cam->image_width <= 0 || cam->image_height <= 0 || cam->sqrt_spp <= 0 || cam->max_depth < 0)
+        return set_err(ctx, RT_ERR_INVALID, "render: bad camera");
+    if ((int64_t)cam->image_width * cam->image_height > (int64_t)1 << 28) return set_err(ctx, RT_ERR_INVALID, "render: image too large");
+    if (cam->sqrt_spp > 46340) return set_err(ctx, RT_ERR_INVALID, "render: sqrt_spp^2 does not fit 32 bits");
+    if (params->precision != RT_PREC_F32 && params->precision != RT_PREC_F64) return set_err(ctx, RT_ERR_INVALID, "bad precision");
+    const int n_strata = cam->sqrt_spp * cam->sqrt_spp;
+    const int s_begin = params->s_begin, s_end = params->s_end < 0 ? n_strata : params->s_end;
+    if (s_begin < 0 || s_end > n_strata || s_begin > s_end) return set_err(ctx, RT_ERR_INVALID, "bad sample range");
+    pl.n_px = (size_t)cam->image_width * cam->image_height;
+    pl.n_samples = s_end - s_begin;
+    RenderLaunch &rl = pl.rl;
+    rl.k0 = (uint32_t)params->seed;
+    rl.k1 = (uint32_t)(params->seed >> 32);
+    rl.s_begin = s_begin;
+    rl.s_end = s_end;
+    rl.n_cus = ctx->n_cus;
+    pl.n_chunks = 0;
+    if (pl.n_samples == 0) return RT_OK;
+    const int n_samples = pl.n_samples;
+    const int tiles = ((cam->image_width + 7) / 8) * ((cam->image_height + RT_TILE_H - 1) / RT_TILE_H);
+    int n_chunks = params->sample_chunks;
+    const int wave_slots = ctx->n_cus * 16;
+    if (n_chunks <= 0 && tiles < 2 * wave_slots) { // small image: equal chunks, enough of them to give every wave ~32 items
+        n_chunks = (wave_slots * 32 + tiles - 1) / tiles;
+        int most = n_samples / 24;
+        if (most < 1) most = 1;
+        if (n_chunks > most) n_chunks = most;
+    }
+    if (max_chunks < 1) max_chunks = 1;
+    const int sched_cap = max_chunks < RT_MAX_SCHED_CHUNKS_HOST ? max_chunks : RT_MAX_SCHED_CHUNKS_HOST;
+    if (n_chunks > 0) {
+        if (n_chunks > n_samples) n_chunks = n_samples;
+        if (n_chunks > 65535) n_chunks = 65535;
+        if (n_chunks > max_chunks) n_chunks = max_chunks;
+        rl.chunk_size = (n_samples + n_chunks - 1) / n_chunks;
+        n_chunks = (n_samples + rl.chunk_size - 1) / rl.chunk_size;
+    } else {
+        const int min_chunk = ctx->min_chunk > 0 ? ctx->min_chunk : (n_samples >= 360 ? 32 : 16);
+        const int divisor = ctx->chunk_divisor > 1 ? ctx->chunk_divisor : (n_samples >= 360 ? 3 : 2); // measured on final_scene 1080p
+        rl.chunk_size = 0;
+        n_chunks = 0;
+        int at = s_begin;
+        rl.chunk_start[0] = at;
+        while (at < s_end) {
+            int left = s_end - at, take = left / divisor;
+            if (ctx->max_chunk > 0 && take > ctx->max_chunk) take = ctx->max_chunk;
+            if (take < min_chunk) take = min_chunk;
+            if (take > left || left - take < min_chunk / 2 || n_chunks == sched_cap - 1) take = left;
+            at += take;
+            rl.chunk_start[++n_chunks] = at;
+        }
+    }
+    rl.n_chunks = n_chunks;
+    pl.n_chunks = n_chunks;
+    return RT_OK;
+}
+
+// Enqueue one planned render on `stream` of the context's device (current on entry): counters cleared, the path-tracing
+// kernel into `partial` (n_chunks > 1) or straight into d_accum, then the fixed-order sum of the partial frames.  Nothing
+// here allocates or synchronises.
+int enqueue_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, int precision, const RenderPlan &pl, float *partial,
+                   unsigned long long *counters, float *d_accum, hipStream_t stream) {
+    if (pl.n_samples == 0) {
+        HIP_TRY(ctx, hipMemsetAsync(d_accum, 0, pl.n_px * 3 * sizeof(float), stream));
+        HIP_TRY(ctx, hipMemsetAsync(counters, 0, 40 * sizeof(unsigned long long), stream));
+        return RT_OK;
+    }
+    float *target = pl.n_chunks > 1 ? partial : d_accum;
+    HIP_TRY(ctx, hipMemsetAsync(counters, 0, 40 * sizeof(unsigned long long), stream));
+    HIP_TRY(ctx, hipMemsetAsync(counters + 37, 0xff, sizeof(unsigned long long), stream)); // [37]: a minimum (diagnostic builds)
+    if (precision == RT_PREC_F64)
+        HIP_TRY(ctx, launch_render<double>(scene->f64.sc, convert_camera<double>(*cam), pl.rl, target, counters, stream));
+    else
+        HIP_TRY(ctx, launch_render<float>(scene->f32.sc, convert_camera<float>(*cam), pl.rl, target, counters, stream));
+    if (pl.n_chunks > 1) HIP_TRY(ctx, launch_reduce_chunks(partial, d_accum, pl.n_px * 3, pl.n_chunks, stream));
+    return RT_OK;
+}
+
+void print_profile(rt_ctx *ctx, const unsigned long long *c) { // diagnostic builds (-DRT_PROFILE_*) fill counters[3..39]
+    if (std::getenv("RT_AMD_PROFILE_ACTIONS")) {
+        const char *nm[6] = {"box", "sphere", "aabox", "medium", "other", "shade"};
+        for (int k = 0; k < 6; k++)
+            std::fprintf(stderr, "[rt_amd profile] %-6s cycles %.4g (%.1f%% of wave time) trips %.4g cyc/trip %.1f lanes/trip %.1f\n",
+                         nm[k], (double)c[4 + 3 * k], 100.0 * (double)c[4 + 3 * k] / (double)(c[3] ? c[3] : 1), (double)c[5 + 3 * k],
+                         (double)c[4 + 3 * k] / (double)(c[5 + 3 * k] ? c[5 + 3 * k] : 1),
+                         (double)c[6 + 3 * k] / (double)(c[5 + 3 * k] ? c[5 + 3 * k] : 1));
+        const char *sn[9] = {"rng begin", "finalize", "material+emit", "metal", "dielectric", "texture", "sample dir", "pdfs+weight", "tail (trav_begin / next_path)"};
+        for (int k = 0; k < 9; k++)
+            std::fprintf(stderr, "[rt_amd profile]   shade/%-30s %.1f%% of wave time\n", sn[k], 100.0 * (double)c[24 + k] / (double)(c[3] ? c[3] : 1));
+        std::fprintf(stderr, "[rt_amd profile] per trip: %.1f lanes idle (item tail), %.1f lanes waiting for shading, of 64; %.1f%% of trips after the item's last unit was dealt\n",
+                     (double)c[33] / (double)(c[35] ? c[35] : 1), (double)c[34] / (double)(c[35] ? c[35] : 1), 100.0 * (double)c[36] / (double)(c[35] ? c[35] : 1));
+    }
+    if (std::getenv("RT_AMD_PROFILE_TAIL")) { // builds with -DRT_PROFILE_TAIL: wave end times
+        const double span = (double)(c[38] - c[37]), n_waves = (double)ctx->n_cus * 16.0;
+        std::fprintf(stderr, "[rt_amd profile] waves busy on average %.1f%% of the kernel's span (first start to last end); wave run time min %.1f%% max %.1f%% of the span\n",
+                     span > 0 ? 100.0 * (double)c[39] / n_waves / span : 0.0, span > 0 ? 100.0 * (double)(~c[35]) / span : 0.0,
+                     span > 0 ? 100.0 * (double)c[36] / span : 0.0);
+    }
+}
+
+// After the work enqueued between ev0 and ev1 has finished: fill `stats` from the events and the kernel's counters.
+int collect_stats(rt_ctx *ctx, const RenderPlan &pl, const unsigned long long *counters, rt_stats *stats) {
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    unsigned long long c[40];
+    HIP_TRY(ctx, hipMemcpy(c, counters, sizeof(c), hipMemcpyDeviceToHost));
+    if (pl.n_samples > 0) print_profile(ctx, c);
+    stats->samples = (uint64_t)pl.n_px * (uint64_t)pl.n_samples;
+    stats->rays = pl.n_samples > 0 ? c[0] : 0;
+    stats->kernel_ms = pl.n_samples > 0 ? ms : 0.0;
+    return RT_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -189,7 +364,7 @@ int rt_init(int device, rt_ctx **out) {
     }
     if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&ctx->counter, 40 * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
-        delete ctx;
+        rt_shutdown(ctx);
         return RT_ERR_HIP;
     }
     hipDeviceProp_t prop;
@@ -205,6 +380,7 @@ void rt_shutdown(rt_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->partial) (void)hipFree(ctx->partial);
     if (ctx->accum) (void)hipFree(ctx->accum);
+    if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->rgb) (void)hipFree(ctx->rgb);
     if (ctx->counter) (void)hipFree(ctx->counter);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -222,12 +398,12 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out) {
     if (!s) return set_err(ctx, RT_ERR_NOMEM, "out of host memory");
     s->ctx = ctx;
     s->n_nodes_desc = desc->n_nodes;
-    int rc = upload_one<float>(ctx, desc, s->f32);
-    if (rc == RT_OK) rc = upload_one<double>(ctx, desc, s->f64);
+    int rc = upload_one<float>(ctx, desc, s->f32); // validates `desc` before anything reads through its pointers
     if (rc != RT_OK) {
         rt_scene_free(s);
         return rc;
     }
+    s->desc.assign(*desc);
     *out = s;
     return RT_OK;
 }
@@ -240,7 +416,7 @@ void rt_scene_free(rt_scene *scene) {
     delete scene;
 }
 
-int rt_scene_info(const rt_scene *scene, int32_t *out /* [4]: flat nodes, lights, f32 bytes, f64 bytes */) {
+int rt_scene_info(const rt_scene *scene, int32_t *out /* [4]: flat nodes, lights, f32 bytes, f64 bytes (0 until first used) */) {
     if (!scene || !out) return RT_ERR_INVALID;
     out[0] = scene->f32.sc.n_units;
     out[1] = scene->f32.sc.n_lights;
@@ -272,6 +448,10 @@ int rt_trace_batch(rt_ctx *ctx, const rt_scene *scene, const rt_ray *rays, const
     if (precision != RT_PREC_F32 && precision != RT_PREC_F64) return set_err(ctx, RT_ERR_INVALID, "bad precision");
     if (n == 0) return RT_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (precision == RT_PREC_F64) {
+        int rc64 = need_f64(ctx, scene);
+        if (rc64) return rc64;
+    }
     rt_ray *d_rays = nullptr;
     double *d_xi = nullptr;
     rt_hit *d_out = nullptr;
@@ -297,117 +477,22 @@ int rt_trace_batch(rt_ctx *ctx, const rt_scene *scene, const rt_ray *rays, const
 int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_params *params,
                      float *d_accum, void *stream_, rt_stats *stats) {
     if (!ctx || !scene || !cam || !params || !d_accum) return set_err(ctx, RT_ERR_INVALID, "rt_render_device: null argument");
-    if (cam->image_width <= 0 || cam->image_height <= 0 || cam->sqrt_spp <= 0 || cam->max_depth < 0)
-        return set_err(ctx, RT_ERR_INVALID, "rt_render_device: bad camera");
-    if ((int64_t)cam->image_width * cam->image_height > (int64_t)1 << 28)
-        return set_err(ctx, RT_ERR_INVALID, "rt_render_device: image too large");
-    if (params->precision != RT_PREC_F32 && params->precision != RT_PREC_F64)
-        return set_err(ctx, RT_ERR_INVALID, "bad precision");
-    const int n_strata = cam->sqrt_spp * cam->sqrt_spp;
-    int s_begin = params->s_begin, s_end = params->s_end <= 0 ? n_strata : params->s_end;
-    if (s_begin < 0 || s_end > n_strata || s_begin > s_end) return set_err(ctx, RT_ERR_INVALID, "bad sample range");
+    RenderPlan pl;
+    int rc = plan_render(ctx, cam, params, 65535, pl);
+    if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t n_px = (size_t)cam->image_width * cam->image_height;
-    const int n_samples = s_end - s_begin;
-    if (n_samples == 0) {
-        HIP_TRY(ctx, hipMemsetAsync(d_accum, 0, n_px * 3 * sizeof(float), stream));
-        if (stats) *stats = rt_stats{0, 0, 0.0};
-        return RT_OK;
-    }
-    // Work decomposition: a work item = (8 x RT_TILE_H pixel tile, chunk of the sample range); waves pull items from a cursor in
-    // chunk-major order.  Default: a DECREASING-size schedule (each chunk takes a half / a third of what is left, down to a minimum),
-    // so the bulk of the samples runs in long items (lanes regenerate paths inside an item; a short item wastes lanes while
-    // its last paths finish) and the kernel ends on short ones (the end-of-kernel imbalance is one short item per wave).
-    // params->sample_chunks > 0 forces that many equal chunks instead.
-    const int tiles = ((cam->image_width + 7) / 8) * ((cam->image_height + RT_TILE_H - 1) / RT_TILE_H);
-    RenderLaunch rl{};
-    int n_chunks = params->sample_chunks;
-    const int wave_slots = ctx->n_cus * 16;
-    if (n_chunks <= 0 && tiles < 2 * wave_slots) { // small image: equal chunks, enough of them to give every wave ~32 items
-        n_chunks = (wave_slots * 32 + tiles - 1) / tiles;
-        int max_chunks = n_samples / 24;
-        if (max_chunks < 1) max_chunks = 1;
-        if (n_chunks > max_chunks) n_chunks = max_chunks;
-    }
-    if (n_chunks > 0) {
-        if (n_chunks > n_samples) n_chunks = n_samples;
-        if (n_chunks > 65535) n_chunks = 65535;
-        rl.chunk_size = (n_samples + n_chunks - 1) / n_chunks;
-        n_chunks = (n_samples + rl.chunk_size - 1) / rl.chunk_size;
-    } else {
-        const int min_chunk = ctx->min_chunk > 0 ? ctx->min_chunk : (n_samples >= 360 ? 32 : 16);
-        const int divisor = ctx->chunk_divisor > 1 ? ctx->chunk_divisor : (n_samples >= 360 ? 3 : 2); // measured on final_scene 1080p
-        rl.chunk_size = 0;
-        n_chunks = 0;
-        int at = s_begin;
-        rl.chunk_start[0] = at;
-        while (at < s_end) {
-            int left = s_end - at, take = left / divisor;
-            if (ctx->max_chunk > 0 && take > ctx->max_chunk) take = ctx->max_chunk;
-            if (take < min_chunk) take = min_chunk;
-            if (take > left || left - take < min_chunk / 2 || n_chunks == 23) take = left;
-            at += take;
-            rl.chunk_start[++n_chunks] = at;
-        }
-    }
-    float *target = d_accum;
-    if (n_chunks > 1) {
-        int rc = ensure(ctx, (void **)&ctx->partial, &ctx->partial_bytes, (size_t)n_chunks * n_px * 3 * sizeof(float));
+    if (params->precision == RT_PREC_F64 && (rc = need_f64(ctx, scene)) != RT_OK) return rc;
+    if (pl.n_chunks > 1) {
+        rc = ensure(ctx, (void **)&ctx->partial, &ctx->partial_bytes, (size_t)pl.n_chunks * pl.n_px * 3 * sizeof(float));
         if (rc) return rc;
-        target = ctx->partial;
     }
-    rl.k0 = (uint32_t)params->seed;
-    rl.k1 = (uint32_t)(params->seed >> 32);
-    rl.s_begin = s_begin;
-    rl.s_end = s_end;
-    rl.n_chunks = n_chunks;
-    rl.n_cus = ctx->n_cus;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->counter, 0, 40 * sizeof(unsigned long long), stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->counter + 37, 0xff, sizeof(unsigned long long), stream)); // [37]: a minimum (diagnostic builds)
     if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    if (params->precision == RT_PREC_F64)
-        HIP_TRY(ctx, launch_render<double>(scene->f64.sc, convert_camera<double>(*cam), rl, target, ctx->counter, stream));
-    else
-        HIP_TRY(ctx, launch_render<float>(scene->f32.sc, convert_camera<float>(*cam), rl, target, ctx->counter, stream));
-    if (n_chunks > 1) HIP_TRY(ctx, launch_reduce_chunks(ctx->partial, d_accum, n_px * 3, n_chunks, stream));
+    rc = enqueue_render(ctx, scene, cam, params->precision, pl, ctx->partial, ctx->counter, d_accum, stream);
+    if (rc) return rc;
     if (stats) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
-        HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
-        float ms = 0;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-        unsigned long long rays = 0;
-        HIP_TRY(ctx, hipMemcpy(&rays, ctx->counter, sizeof(rays), hipMemcpyDeviceToHost));
-        if (std::getenv("RT_AMD_PROFILE_ACTIONS")) { // diagnostic builds (-DRT_PROFILE_ACTIONS) fill counters[4..13]
-            unsigned long long c[40];
-            HIP_TRY(ctx, hipMemcpy(c, ctx->counter, sizeof(c), hipMemcpyDeviceToHost));
-            const char *nm[6] = {"box", "sphere", "aabox", "medium", "other", "shade"};
-            for (int k = 0; k < 6; k++)
-                std::fprintf(stderr, "[rt_amd profile] %-6s cycles %.4g (%.1f%% of wave time) trips %.4g cyc/trip %.1f lanes/trip %.1f\n",
-                             nm[k], (double)c[4 + 3 * k], 100.0 * (double)c[4 + 3 * k] / (double)(c[3] ? c[3] : 1), (double)c[5 + 3 * k],
-                             (double)c[4 + 3 * k] / (double)(c[5 + 3 * k] ? c[5 + 3 * k] : 1),
-                             (double)c[6 + 3 * k] / (double)(c[5 + 3 * k] ? c[5 + 3 * k] : 1));
-        }
-        if (std::getenv("RT_AMD_PROFILE_ACTIONS")) {
-            unsigned long long c[40];
-            HIP_TRY(ctx, hipMemcpy(c, ctx->counter, sizeof(c), hipMemcpyDeviceToHost));
-            const char *nm[9] = {"rng begin", "finalize", "material+emit", "metal", "dielectric", "texture", "sample dir", "pdfs+weight", "tail (trav_begin / next_path)"};
-            for (int k = 0; k < 9; k++)
-                std::fprintf(stderr, "[rt_amd profile]   shade/%-30s %.1f%% of wave time\n", nm[k], 100.0 * (double)c[24 + k] / (double)(c[3] ? c[3] : 1));
-            std::fprintf(stderr, "[rt_amd profile] per trip: %.1f lanes idle (item tail), %.1f lanes waiting for shading, of 64; %.1f%% of trips after the item's last unit was dealt\n",
-                         (double)c[33] / (double)(c[35] ? c[35] : 1), (double)c[34] / (double)(c[35] ? c[35] : 1), 100.0 * (double)c[36] / (double)(c[35] ? c[35] : 1));
-        }
-        if (std::getenv("RT_AMD_PROFILE_TAIL")) { // builds with -DRT_PROFILE_TAIL: wave end times
-            unsigned long long c[40];
-            HIP_TRY(ctx, hipMemcpy(c, ctx->counter, sizeof(c), hipMemcpyDeviceToHost));
-            const double span = (double)(c[38] - c[37]), n_waves = (double)ctx->n_cus * 16.0;
-            std::fprintf(stderr, "[rt_amd profile] waves busy on average %.1f%% of the kernel's span (first start to last end); wave run time min %.1f%% max %.1f%% of the span\n",
-                         span > 0 ? 100.0 * (double)c[39] / n_waves / span : 0.0, span > 0 ? 100.0 * (double)(~c[35]) / span : 0.0,
-                         span > 0 ? 100.0 * (double)c[36] / span : 0.0);
-        }
-        stats->samples = (uint64_t)n_px * (uint64_t)n_samples;
-        stats->rays = rays;
-        stats->kernel_ms = ms;
+        return collect_stats(ctx, pl, ctx->counter, stats);
     }
     return RT_OK;
 }
@@ -416,6 +501,22 @@ int rt_tonemap_device(rt_ctx *ctx, const float *d_accum, double scale, size_t n_
     if (!ctx || !d_accum || !d_rgb8) return set_err(ctx, RT_ERR_INVALID, "rt_tonemap_device: null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_tonemap(d_accum, scale, n_pixels * 3, d_rgb8, (hipStream_t)stream));
+    return RT_OK;
+}
+
+// accum (device, on ctx's device) -> the caller's host buffers
+static int finish_to_host(rt_ctx *ctx, const rt_camera *cam, float *accum_rgb, uint8_t *rgb8) {
+    const size_t n_px = (size_t)cam->image_width * cam->image_height;
+    if (accum_rgb) HIP_TRY(ctx, hipMemcpy(accum_rgb, ctx->accum, n_px * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (rgb8) {
+        int rc = ensure(ctx, (void **)&ctx->rgb, &ctx->rgb_bytes, n_px * 3);
+        if (rc) return rc;
+        const double scale = 1.0 / ((double)cam->sqrt_spp * cam->sqrt_spp); // camera.h:215 pixel_samples_scale
+        rc = rt_tonemap_device(ctx, ctx->accum, scale, n_px, ctx->rgb, nullptr);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        HIP_TRY(ctx, hipMemcpy(rgb8, ctx->rgb, n_px * 3, hipMemcpyDeviceToHost));
+    }
     return RT_OK;
 }
 
@@ -432,17 +533,73 @@ int rt_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt
     rc = rt_render_device(ctx, scene, cam, params, ctx->accum, nullptr, &st);
     if (rc) return rc;
     if (stats) *stats = st;
-    if (accum_rgb) HIP_TRY(ctx, hipMemcpy(accum_rgb, ctx->accum, n_px * 3 * sizeof(float), hipMemcpyDeviceToHost));
-    if (rgb8) {
-        rc = ensure(ctx, (void **)&ctx->rgb, &ctx->rgb_bytes, n_px * 3);
-        if (rc) return rc;
-        const double scale = 1.0 / ((double)cam->sqrt_spp * cam->sqrt_spp); // camera.h:215 pixel_samples_scale
-        rc = rt_tonemap_device(ctx, ctx->accum, scale, n_px, ctx->rgb, nullptr);
-        if (rc) return rc;
-        HIP_TRY(ctx, hipDeviceSynchronize());
-        HIP_TRY(ctx, hipMemcpy(rgb8, ctx->rgb, n_px * 3, hipMemcpyDeviceToHost));
+    return finish_to_host(ctx, cam, accum_rgb, rgb8);
+}
+
+int rt_render_multi(rt_ctx *const *ctxs, const rt_scene *const *scenes, int n_devices, const rt_camera *cam,
+                    const rt_render_params *params, float *accum_rgb, uint8_t *rgb8, rt_stats *stats) {
+    if (!ctxs || !scenes || n_devices < 1 || !ctxs[0]) return RT_ERR_INVALID;
+    rt_ctx *root = ctxs[0];
+    if (!cam || !params) return set_err(root, RT_ERR_INVALID, "rt_render_multi: null argument");
+    if (n_devices > 64) return set_err(root, RT_ERR_INVALID, "rt_render_multi: more than 64 contexts");
+    for (int k = 0; k < n_devices; k++)
+        if (!ctxs[k] || !scenes[k] || scenes[k]->ctx != ctxs[k])
+            return set_err(root, RT_ERR_INVALID, "rt_render_multi: scenes[k] must have been uploaded through ctxs[k]");
+    for (int k = 0; k < n_devices; k++)
+        for (int j = 0; j < k; j++)
+            if (ctxs[j] == ctxs[k]) // a context's buffers, counters and events serve one launch at a time
+                return set_err(root, RT_ERR_INVALID, "rt_render_multi: the same context is listed twice (create one per entry)");
+    RenderPlan whole;
+    int rc = plan_render(root, cam, params, 65535, whole); // validates the camera and the range once
+    if (rc) return rc;
+    const int s_begin = whole.rl.s_begin, n_samples = whole.n_samples;
+    const size_t n_px = whole.n_px, bytes = n_px * 3 * sizeof(float);
+    // enqueue every device's share: strata [s_begin + k*n/G, s_begin + (k+1)*n/G); nothing below waits until all are running
+    std::vector<RenderPlan> plans((size_t)n_devices);
+    auto fail_from = [&](int k, int code) { // report a context's error through the root context
+        if (k != 0) root->err = "device " + std::to_string(ctxs[k]->device) + ": " + ctxs[k]->err;
+        return code;
+    };
+    for (int k = 0; k < n_devices; k++) {
+        rt_ctx *c = ctxs[k];
+        rt_render_params p = *params;
+        p.s_begin = s_begin + (int)(((int64_t)k * n_samples) / n_devices);
+        p.s_end = s_begin + (int)(((int64_t)(k + 1) * n_samples) / n_devices);
+        if ((rc = plan_render(c, cam, &p, 65535, plans[k])) != RT_OK) return fail_from(k, rc);
+        if (hipSetDevice(c->device) != hipSuccess) return fail_from(k, set_err(c, RT_ERR_HIP, "hipSetDevice failed"));
+        if (params->precision == RT_PREC_F64 && (rc = need_f64(c, scenes[k])) != RT_OK) return fail_from(k, rc);
+        if ((rc = ensure(c, (void **)&c->accum, &c->accum_bytes, bytes)) != RT_OK) return fail_from(k, rc);
+        if (plans[k].n_chunks > 1 &&
+            (rc = ensure(c, (void **)&c->partial, &c->partial_bytes, (size_t)plans[k].n_chunks * bytes)) != RT_OK)
+            return fail_from(k, rc);
+        if (hipEventRecord(c->ev0, nullptr) != hipSuccess) return fail_from(k, set_err(c, RT_ERR_HIP, "hipEventRecord failed"));
+        if ((rc = enqueue_render(c, scenes[k], cam, params->precision, plans[k], c->partial, c->counter, c->accum, nullptr)) != RT_OK)
+            return fail_from(k, rc);
+        if (hipEventRecord(c->ev1, nullptr) != hipSuccess) return fail_from(k, set_err(c, RT_ERR_HIP, "hipEventRecord failed"));
     }
-    return RT_OK;
+    rt_stats total{};
+    for (int k = 0; k < n_devices; k++) {
+        rt_ctx *c = ctxs[k];
+        rt_stats st{};
+        if (hipSetDevice(c->device) != hipSuccess) return fail_from(k, set_err(c, RT_ERR_HIP, "hipSetDevice failed"));
+        if ((rc = collect_stats(c, plans[k], c->counter, &st)) != RT_OK) return fail_from(k, rc);
+        total.samples += st.samples;
+        total.rays += st.rays;
+        if (st.kernel_ms > total.kernel_ms) total.kernel_ms = st.kernel_ms; // the devices run side by side
+    }
+    // the exchange step: the peers' sums are added onto the root device in context order (a fixed order: the frame repeats)
+    HIP_TRY(root, hipSetDevice(root->device));
+    if (n_devices > 1) {
+        rc = ensure(root, (void **)&root->stage, &root->stage_bytes, bytes);
+        if (rc) return rc;
+    }
+    for (int k = 1; k < n_devices; k++) {
+        HIP_TRY(root, hipMemcpyPeer(root->stage, root->device, ctxs[k]->accum, ctxs[k]->device, bytes));
+        HIP_TRY(root, launch_add_into(root->accum, root->stage, n_px * 3, nullptr));
+    }
+    HIP_TRY(root, hipDeviceSynchronize());
+    if (stats) *stats = total;
+    return finish_to_host(root, cam, accum_rgb, rgb8);
 }
 
 } // extern "C"

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/rt_amd.h"
@@ -109,6 +110,48 @@ template <class R> class Flattener {
             default: ok = false;
             }
             if (!ok) return fail(RT_ERR_INVALID, "node " + std::to_string(i) + ": bad kind or index");
+        }
+        // The graph must be acyclic (shared subtrees are fine: the reference's final_scene lists one boundary sphere twice).
+        // Iterative three-colour depth-first search from both roots: a child that is still open when it is met again
+        // closes a cycle.
+        {
+            std::vector<uint8_t> colour((size_t)d_.n_nodes, 0); // 0 new, 1 open, 2 done
+            std::vector<std::pair<int, int>> stack;             // (node, next child slot)
+            auto n_children = [&](const rt_node &n) {
+                switch (n.kind) {
+                case RT_NODE_BVH: return 2;
+                case RT_NODE_LIST: return (int)n.b;
+                case RT_NODE_TRANSLATE:
+                case RT_NODE_ROTATE_Y:
+                case RT_NODE_MEDIUM: return 1;
+                default: return 0;
+                }
+            };
+            auto child = [&](const rt_node &n, int k) {
+                if (n.kind == RT_NODE_BVH) return k == 0 ? n.a : n.b;
+                if (n.kind == RT_NODE_LIST) return (int)d_.child_index[n.a + k];
+                return n.a;
+            };
+            for (int root : {d_.world_root, d_.lights_root}) {
+                if (colour[root]) continue;
+                colour[root] = 1;
+                stack.push_back({root, 0});
+                while (!stack.empty()) {
+                    auto &[id, k] = stack.back();
+                    const rt_node &n = d_.nodes[id];
+                    if (k == n_children(n)) {
+                        colour[id] = 2;
+                        stack.pop_back();
+                        continue;
+                    }
+                    const int c = child(n, k++);
+                    if (colour[c] == 1) return fail(RT_ERR_INVALID, "scene graph has a cycle through node " + std::to_string(c));
+                    if (colour[c] == 0) {
+                        colour[c] = 1;
+                        stack.push_back({c, 0});
+                    }
+                }
+            }
         }
         for (int i = 0; i < d_.n_materials; i++) {
             const rt_material &m = d_.materials[i];

@@ -277,8 +277,8 @@ RT_DEV bool box_hit(const UnitT<R> &u0, const UnitT<R> &u1, V3<R> o, V3<R> inv, 
     const R bx0 = u0.w[0], bx1 = u0.w[1], by0 = u0.w[2], by1 = u0.w[3], bz0 = u1.w[0], bz1 = u1.w[1];
     if constexpr (sizeof(R) == 4) {
         // (min, max) pairs sit in adjacent registers: one v_pk_fma_f32 does both slab planes of an axis, (b - o) * inv
-        // as b * inv + (-o * inv).  A direction component that is exactly zero makes the axis' distances NaN instead of
-        // +-inf; min / max drop NaNs, so that axis then always passes: conservative for a bounding box (leaves are exact).
+        // as b * inv + (-o * inv).  inv is finite (inv_dir_trav): a ray parallel to the slab gets +-1e30-sized distances with
+        // the signs of b - o, i.e. the axis passes exactly when the origin lies inside the slab, as in the reference.
         const rt_f2 tx = rt_f2{bx0, bx1} * inv.x + noi.x, ty = rt_f2{by0, by1} * inv.y + noi.y, tz = rt_f2{bz0, bz1} * inv.z + noi.z;
         R tn = m_max(m_max(m_min(tx.x, tx.y), m_min(ty.x, ty.y)), m_max(m_min(tz.x, tz.y), tmin));
         // (tmax is the closest hit so far, a value the compiler cannot prove canonical: through fminf it would first be
@@ -470,6 +470,20 @@ template <class R, class SC> RT_DEV RayT<R> ray_in_ctx(const SC &sc, const RayT<
 }
 
 template <class R> RT_DEV V3<R> inv_dir(V3<R> d) { return mk<R>(m_rcp(d.x), m_rcp(d.y), m_rcp(d.z)); } // aabb.h:42
+// The inverse direction the TRAVERSAL keeps.  double: the reference's 1.0 / d (+-inf for a zero component; (b - o) * inf has
+// the sign of b - o, aabb.h:42-53).  float: the slab distances are evaluated as b * inv + (-o * inv), where an infinite inv
+// turns one plane of the axis into inf - inf = NaN and the slab into a reject although the origin lies inside it; |inv| is
+// therefore kept finite (one v_med3_f32 per component per ray): b * 1e30 - o * 1e30 keeps the sign of b - o for every
+// coordinate below 3e8, which is all the slab test needs of a ray parallel to the slab.
+template <class R> RT_DEV V3<R> inv_dir_trav(V3<R> d) {
+    V3<R> inv = inv_dir(d);
+    if constexpr (sizeof(R) == 4) {
+        inv.x = __builtin_amdgcn_fmed3f(inv.x, -1e30f, 1e30f);
+        inv.y = __builtin_amdgcn_fmed3f(inv.y, -1e30f, 1e30f);
+        inv.z = __builtin_amdgcn_fmed3f(inv.z, -1e30f, 1e30f);
+    }
+    return inv;
+}
 
 // Per-ray traversal state of world.hit(r, interval(tmin, inf), rec): a cursor into the threaded stream (pre-order ==
 // the reference's recursion order), the ray in the current transform context and the closest hit so far.
@@ -499,7 +513,7 @@ template <class R, bool ALL_LDS>
 RT_DEV void trav_begin(const Mem<R, ALL_LDS> &mem, Trav<R> &tv, const RayT<R> &world) {
     tv.o = world.o;
     tv.d = world.d;
-    tv.inv = inv_dir(world.d);
+    tv.inv = inv_dir_trav(world.d);
     if constexpr (sizeof(R) == 4) tv.noi = -(tv.o * tv.inv);
     tv.best_t = Const<R>::inf;
     tv.best_off = -1;
@@ -562,7 +576,7 @@ RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SC &sc, Trav<R> &tv
         }
     } else if (kind == K_XF_ENTER) {
         xf_apply(ldi(tv.u1.w[0]), tv.u0.w[0], tv.u0.w[1], tv.u0.w[2], tv.o, tv.d);
-        tv.inv = inv_dir(tv.d);
+        tv.inv = inv_dir_trav(tv.d);
         if constexpr (sizeof(R) == 4) tv.noi = -(tv.o * tv.inv);
         tv.ctx = ldi(tv.u1.w[1]);
     } else if (kind == K_XF_EXIT) {
@@ -576,7 +590,7 @@ RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SC &sc, Trav<R> &tv
                 tv.o = mk<R>((c * tv.o.x) + (s * tv.o.z), tv.o.y, (c * tv.o.z) - (s * tv.o.x));
                 tv.d = mk<R>((c * tv.d.x) + (s * tv.d.z), tv.d.y, (c * tv.d.z) - (s * tv.d.x));
             }
-            tv.inv = inv_dir(tv.d);
+            tv.inv = inv_dir_trav(tv.d);
             tv.noi = -(tv.o * tv.inv);
         } else { // the reference's outer ray is untouched by the instance (hittable.h:53-65): restore it exactly
             const RayT<R> r = ray_in_ctx(sc, world, tv.ctx);

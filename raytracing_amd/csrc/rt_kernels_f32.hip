@@ -24,6 +24,12 @@ __global__ void tonemap_kernel(const float *__restrict__ accum, double scale, si
     rgb[k] = (uint8_t)int(256 * x);
 }
 
+// rt_render_multi's exchange step: a peer device's sums, copied next to the root's, are added onto them.
+__global__ void add_into_kernel(float *__restrict__ dst, const float *__restrict__ src, size_t n) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) dst[k] += src[k];
+}
+
 template hipError_t launch_render<float>(const SceneT<float> &, const CameraT<float> &, const RenderLaunch &, float *,
                                          unsigned long long *, hipStream_t);
 template hipError_t launch_trace<float>(const SceneT<float> &, const rt_ray *, const double *, size_t, rt_hit *, uint32_t,
@@ -32,6 +38,12 @@ template hipError_t launch_trace<float>(const SceneT<float> &, const rt_ray *, c
 hipError_t launch_reduce_chunks(const float *partial, float *out, size_t n, int n_chunks, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, out, n, n_chunks);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_into(float *dst, const float *src, size_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(add_into_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, src, n);
     return hipGetLastError();
 }
 

@@ -8,6 +8,7 @@
 
 namespace rtamd {
 
+enum : int { RT_MAX_SCHED_CHUNKS_HOST = 24 }; // == RT_MAX_SCHED_CHUNKS of rt_kernels.h (static_assert in rt_launch_impl.h)
 struct RenderLaunch {
     uint32_t k0, k1;
     int32_t s_begin, s_end, chunk_size, n_chunks;
@@ -34,6 +35,7 @@ hipError_t launch_trace(const SceneT<R> &sc, const rt_ray *d_rays, const double 
                         uint32_t k0, uint32_t k1, int n_cus, hipStream_t stream);
 hipError_t launch_reduce_chunks(const float *partial, float *out, size_t n, int n_chunks, hipStream_t stream);
 hipError_t launch_tonemap(const float *accum, double scale, size_t n, uint8_t *rgb, hipStream_t stream);
+hipError_t launch_add_into(float *dst, const float *src, size_t n, hipStream_t stream); // dst[k] += src[k]
 
 } // namespace rtamd
 #endif

@@ -5,6 +5,7 @@
 #include "rt_launch.h"
 
 namespace rtamd {
+static_assert(RT_MAX_SCHED_CHUNKS_HOST == RT_MAX_SCHED_CHUNKS, "chunk schedule capacity");
 
 // A kernel that asks for more than 64 KiB of dynamic LDS must say so once.
 template <class K> hipError_t allow_lds(K kernel, int bytes) {

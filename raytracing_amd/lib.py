@@ -16,7 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")  # RT_AMD_LIB: diagnostic builds
 
 EXPORTS = ["rt_abi_sizeof", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_upload", "rt_scene_free",
-           "rt_scene_info", "rt_scene_flatten_info", "rt_trace_batch", "rt_render_device", "rt_tonemap_device", "rt_render"]
+           "rt_scene_info", "rt_scene_flatten_info", "rt_trace_batch", "rt_render_device", "rt_tonemap_device", "rt_render",
+           "rt_render_multi"]
 
 _lib = None
 
@@ -58,6 +59,9 @@ def load() -> C.CDLL:
     L.rt_tonemap_device.argtypes = [vp, vp, C.c_double, C.c_size_t, vp, vp]
     L.rt_render.restype = C.c_int
     L.rt_render.argtypes = [vp, vp, vp, C.POINTER(abi.RenderParams), vp, vp, C.POINTER(abi.Stats)]
+    L.rt_render_multi.restype = C.c_int
+    L.rt_render_multi.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int, vp, C.POINTER(abi.RenderParams), vp, vp,
+                                  C.POINTER(abi.Stats)]
     _lib = L
     return L
 
@@ -146,7 +150,7 @@ class DeviceScene:
         self.ctx.check(rc, "rt_trace_batch")
         return out
 
-    def render(self, camera: np.ndarray, seed: int = 0, s_begin: int = 0, s_end: int = 0,
+    def render(self, camera: np.ndarray, seed: int = 0, s_begin: int = 0, s_end: int = abi.RT_ALL_STRATA,
                precision: int = abi.RT_PREC_F32, sample_chunks: int = 0, want_rgb8: bool = True):
         """Host-buffer render through rt_render: returns (accum[H,W,3] float32 sums, rgb8[H,W,3] or None, stats)."""
         cam = np.ascontiguousarray(camera, dtype=abi.camera_dtype).reshape(1)
@@ -160,7 +164,7 @@ class DeviceScene:
         self.ctx.check(rc, "rt_render")
         return accum, rgb, {"samples": st.samples, "rays": st.rays, "kernel_ms": st.kernel_ms}
 
-    def render_device(self, camera: np.ndarray, d_accum_ptr: int, seed: int = 0, s_begin: int = 0, s_end: int = 0,
+    def render_device(self, camera: np.ndarray, d_accum_ptr: int, seed: int = 0, s_begin: int = 0, s_end: int = abi.RT_ALL_STRATA,
                       precision: int = abi.RT_PREC_F32, sample_chunks: int = 0, stream: int = 0, want_stats: bool = False):
         """Device-buffer render through rt_render_device (d_accum_ptr: device address of H*W*3 floats)."""
         cam = np.ascontiguousarray(camera, dtype=abi.camera_dtype).reshape(1)
@@ -174,3 +178,23 @@ class DeviceScene:
     def tonemap_device(self, d_accum_ptr: int, scale: float, n_pixels: int, d_rgb_ptr: int, stream: int = 0):
         rc = self.ctx.L.rt_tonemap_device(self.ctx.h, d_accum_ptr, scale, n_pixels, d_rgb_ptr, stream or None)
         self.ctx.check(rc, "rt_tonemap_device")
+
+
+def render_multi(scenes: list, camera: np.ndarray, seed: int = 0, s_begin: int = 0, s_end: int = abi.RT_ALL_STRATA,
+                 precision: int = abi.RT_PREC_F32, sample_chunks: int = 0, want_rgb8: bool = True):
+    """One frame on several contexts from this process (rt_render_multi): `scenes` = the same scene uploaded through one
+    Context per device (two contexts may share a device).  Returns what DeviceScene.render returns."""
+    cam = np.ascontiguousarray(camera, dtype=abi.camera_dtype).reshape(1)
+    W, H = int(cam["image_width"][0]), int(cam["image_height"][0])
+    accum = np.zeros((H, W, 3), dtype=np.float32)
+    rgb = np.zeros((H, W, 3), dtype=np.uint8) if want_rgb8 else None
+    p = abi.RenderParams(seed, s_begin, s_end, precision, sample_chunks)
+    st = abi.Stats()
+    n = len(scenes)
+    ctxs = (C.c_void_p * n)(*[ds.ctx.h for ds in scenes])
+    hs = (C.c_void_p * n)(*[ds.h for ds in scenes])
+    root = scenes[0].ctx
+    rc = root.L.rt_render_multi(ctxs, hs, n, cam.ctypes.data, C.byref(p), accum.ctypes.data,
+                                rgb.ctypes.data if want_rgb8 else None, C.byref(st))
+    root.check(rc, "rt_render_multi")
+    return accum, rgb, {"samples": st.samples, "rays": st.rays, "kernel_ms": st.kernel_ms}

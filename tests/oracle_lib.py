@@ -57,7 +57,7 @@ def trace_batch(scene: abi.Scene, rays: np.ndarray, xi: np.ndarray | None):
     return out, counters
 
 
-def render(scene: abi.Scene, camera: np.ndarray, seed: int = 0, s_begin: int = 0, s_end: int = 0, rng_mode: int = 1,
+def render(scene: abi.Scene, camera: np.ndarray, seed: int = 0, s_begin: int = 0, s_end: int = -1, rng_mode: int = 1,
            threads: int = 1):
     """Returns (accum[H,W,3] float64 unscaled sums, counters[6] = aabb,sphere,quad,tri,rays,samples)."""
     cam = np.ascontiguousarray(camera, dtype=abi.camera_dtype).reshape(1)

@@ -123,3 +123,22 @@ def test_flattener_stream_sizes_and_box_fusion():
     bad.world_root = 10 ** 6
     with pytest.raises(lib.RtError):
         lib.flatten_info(bad)
+
+
+def test_flattener_refuses_cyclic_graphs():
+    """A node that reaches itself (a bvh_node whose child is the node, a list that lists an ancestor) is refused with a
+    status; shared subtrees (a DAG, as the reference's final_scene has) are fine."""
+    sc = fx.scene(2)
+    bvh = np.nonzero(sc.nodes["kind"] == abi.RT_NODE_BVH)[0]
+    assert len(bvh) > 2
+    bad = fx.scene(2)
+    bad.nodes["a"][bvh[1]] = bvh[1]  # self reference
+    with pytest.raises(lib.RtError):
+        lib.flatten_info(bad)
+    bad = fx.scene(2)
+    bad.nodes["b"][bvh[-1]] = sc.world_root  # back edge to the root
+    with pytest.raises(lib.RtError):
+        lib.flatten_info(bad)
+    dag = fx.scene(2)
+    dag.nodes["b"][bvh[-1]] = dag.nodes["a"][bvh[-1]]  # the same child twice: legal (bvh.h:30 does it for span 1)
+    lib.flatten_info(dag)

@@ -1,0 +1,190 @@
+"""GPU (-m gpu): the multi-GPU paths on the one GPU a test box has.
+
+* rt_render_multi (one process, one context per device): the device list [0, 0] -- two contexts on the same GPU -- must
+  give the single-context frame with the same number of rays; in f64 the oracle's frame.
+* bench.py --gpus 2: the launcher starts two ranks itself; with RT_AMD_DEVICE_MAP=0,0 both use GPU 0 (RCCL refuses two
+  ranks on one device, so that rehearsal reduces through host memory with gloo; one rank per device uses RCCL).
+* the ABI corners ADVICE.md (round 1) named: axis-parallel rays in f32, the empty stratum range [0, 0).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from raytracing_amd import abi, lib
+from tests import fixtures as fx
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def two_contexts(gpu_ctx):
+    other = lib.Context(0)
+    yield [gpu_ctx, other]
+    other.close()
+
+
+@pytest.fixture(scope="module")
+def third_context():
+    c = lib.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_render_multi_two_contexts_equal_single_context(two_contexts, third_context, n):
+    sc = fx.scene(n)
+    cam, _, _, _ = fx.img(n)
+    cam = fx.with_size(cam, sqrt_spp=5, max_depth=10)
+    scenes = [c.upload(sc) for c in two_contexts]
+    try:
+        whole, rgb1, st1 = scenes[0].render(cam, seed=5, precision=abi.RT_PREC_F32)
+        both, rgb2, st2 = lib.render_multi(scenes, cam, seed=5, precision=abi.RT_PREC_F32)
+        assert st2["rays"] == st1["rays"] and st2["samples"] == st1["samples"] == 32 * 18 * 25
+        ok = np.isfinite(whole)
+        assert np.array_equal(ok, np.isfinite(both))
+        np.testing.assert_allclose(both[ok], whole[ok], rtol=2e-6, atol=1e-6)
+        assert (np.abs(rgb2.astype(int) - rgb1.astype(int)) <= 1).all()
+        again, _, _ = lib.render_multi(scenes, cam, seed=5, precision=abi.RT_PREC_F32)
+        assert again.tobytes() == both.tobytes(), "fixed exchange order: the frame repeats"
+        # a sub-range split three ways, in the reference arithmetic, against the oracle
+        scenes.append(third_context.upload(sc))
+        want, cnt = O.render(sc, cam, seed=5, s_begin=3, s_end=22, rng_mode=1, threads=8)
+        got, _, st = lib.render_multi(scenes, cam, seed=5, s_begin=3, s_end=22, precision=abi.RT_PREC_F64)
+        assert st["rays"] == int(cnt[4]) and st["samples"] == int(cnt[5])
+        rel = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-3)
+        assert np.nanmax(rel) <= 1e-6
+        # more contexts than strata: the empty shares contribute nothing
+        tiny, _, st = lib.render_multi(scenes, cam, seed=5, s_begin=7, s_end=8, precision=abi.RT_PREC_F32)
+        with pytest.raises(lib.RtError):  # one context listed twice: its buffers and counters serve one launch at a time
+            lib.render_multi([scenes[0], scenes[1], scenes[0]], cam, seed=5)
+        one, _, st0 = scenes[0].render(cam, seed=5, s_begin=7, s_end=8, precision=abi.RT_PREC_F32)
+        assert st["rays"] == st0["rays"] and tiny.tobytes() == one.tobytes()
+    finally:
+        for ds in scenes:
+            ds.close()
+
+
+def test_render_multi_rejects_mismatched_scene(two_contexts):
+    sc = fx.scene(2)
+    cam, _, _, _ = fx.img(2)
+    ds = two_contexts[0].upload(sc)
+    try:
+        with pytest.raises(lib.RtError):
+            _multi_with_ctxs(two_contexts, [ds, ds], cam)
+    finally:
+        ds.close()
+
+
+def _multi_with_ctxs(ctxs, scenes, cam):
+    """rt_render_multi with scenes[1] uploaded through a different context than ctxs[1]: must be refused."""
+    import ctypes as C
+    L = ctxs[0].L
+    cam = np.ascontiguousarray(cam, dtype=abi.camera_dtype).reshape(1)
+    p = abi.RenderParams(1, 0, abi.RT_ALL_STRATA, abi.RT_PREC_F32, 0)
+    W, H = int(cam["image_width"][0]), int(cam["image_height"][0])
+    acc = np.zeros((H, W, 3), dtype=np.float32)
+    cs = (C.c_void_p * 2)(ctxs[0].h, ctxs[1].h)
+    hs = (C.c_void_p * 2)(scenes[0].h, scenes[1].h)
+    rc = L.rt_render_multi(cs, hs, 2, cam.ctypes.data, C.byref(p), acc.ctypes.data, None, None)
+    ctxs[0].check(rc, "rt_render_multi")
+
+
+def test_empty_range_at_zero_renders_nothing(gpu_ctx):
+    """[0, 0) is an EMPTY range (what split_range gives rank 0 when there are fewer strata than ranks), not "all"."""
+    ds = gpu_ctx.upload(fx.scene(2))
+    cam, _, _, _ = fx.img(2)
+    try:
+        empty, _, st = ds.render(cam, seed=9, s_begin=0, s_end=0)
+        assert st["samples"] == 0 and st["rays"] == 0 and not empty.any()
+        whole, _, st = ds.render(cam, seed=9)  # s_end = RT_ALL_STRATA
+        assert st["samples"] == 32 * 18 * 9 and whole.any()
+        big = fx.with_size(cam, sqrt_spp=46341)
+        with pytest.raises(lib.RtError):
+            ds.render(big, seed=9, s_begin=0, s_end=1)
+    finally:
+        ds.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4])
+def test_axis_parallel_rays_f32_ids_equal_f64(gpu_ctx, n):
+    """Rays with an exactly zero (or negative-zero) direction component: the f32 slab test keeps 1/d finite so that a ray
+    parallel to a slab passes it exactly when its origin lies inside (aabb.h:42-53 gets that from (b - o) * inf)."""
+    sc = fx.scene(n)
+    ds = gpu_ctx.upload(sc)
+    try:
+        cam = sc.camera[0]
+        c = np.array(cam["center"], dtype=np.float64)
+        p00 = np.array(cam["pixel00_loc"], dtype=np.float64)
+        du, dv = np.array(cam["pixel_delta_u"]), np.array(cam["pixel_delta_v"])
+        W, H = int(cam["image_width"]), int(cam["image_height"])
+        target = p00 + du * (W / 2) + dv * (H / 2)  # the point the camera looks at
+        rng = np.random.default_rng(5)
+        rays = []
+        for k in range(600):
+            if k % 2 == 0:  # from the eye towards the scene, one or two components zeroed
+                o = c + rng.normal(size=3) * 0.01 * np.abs(c).max()
+                d = (target - c) + rng.normal(size=3) * np.linalg.norm(target - c) * 0.3
+            else:  # from inside the scene's volume
+                o = target + rng.normal(size=3) * np.linalg.norm(target - c) * 0.5
+                d = rng.normal(size=3)
+            z = rng.integers(0, 3)
+            d[z] = 0.0 if k % 4 < 2 else -0.0
+            if k % 3 == 0:
+                d[(z + 1) % 3] = 0.0
+            rays.append((o, d, 0.5))
+        # the six axis directions from (next to) the eye.  Not from the eye itself: final_scene's camera sits at z = -600,
+        # exactly in the plane two ground boxes share, where the reference's own answer hangs on 0 * inf = NaN (aabb.h:42)
+        eye = c + np.array([0.37, 0.11, 0.23])
+        rays += [(eye, np.array(v, dtype=np.float64), 0.0) for v in ((0, 0, -1), (0, 0, 1), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (-0.0, -1, 0))]
+        arr = np.zeros(len(rays), dtype=abi.ray_dtype)
+        for k, (o, d, tm) in enumerate(rays):
+            arr["orig"][k], arr["dir"][k], arr["time"][k] = o, d, tm
+        xi = np.full(len(rays), 0.37)
+        h64 = ds.trace_batch(arr, xi, abi.RT_PREC_F64)
+        h32 = ds.trace_batch(arr, xi, abi.RT_PREC_F32)
+        want, _ = O.trace_batch(sc, arr, xi)
+        assert (h64["prim"] == want["prim"]).all()
+        assert (h64["prim"] >= 0).sum() >= 100, "the batch must hit things"
+        diff = np.nonzero(h32["prim"] != h64["prim"])[0]
+        # float may lose a grazing hit or swap an equal-distance tie, never a whole subtree: every difference must be a
+        # near-tie (the other primitive within 1e-4 relative) or a hit whose f64 distance is a grazing one
+        for k in diff:
+            a, b = h32[k], h64[k]
+            if a["prim"] >= 0 and b["prim"] >= 0:
+                assert abs(a["t"] - b["t"]) <= 1e-4 * abs(b["t"]), (k, a["prim"], b["prim"], a["t"], b["t"])
+        assert len(diff) <= 6, f"{len(diff)} of {len(rays)} axis-parallel rays differ"
+    finally:
+        ds.close()
+
+
+def test_bench_gpus_2_launches_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` starts its own ranks: n_gpus must be the world size actually formed, the
+    image must not depend on it (same rays per sample as one rank), and the C++ drop-in must run on the device list."""
+    env = dict(os.environ, RT_AMD_DEVICE_MAP="0,0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None)
+    common = ["--steps", "1", "--warmup", "1", "--config", "cornell", "--width", "96", "--height", "96", "--spp", "64",
+              "--depth", "12", "--no-cpu-baseline"]
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *common], env=env, cwd=tmp_path,
+                        capture_output=True, text=True, timeout=280)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    lines = [ln for ln in r2.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r2.stdout
+    two = json.loads(lines[0])
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common], env=env, cwd=tmp_path,
+                        capture_output=True, text=True, timeout=280)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    one = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["samples_per_step"] == one["config"]["samples_per_step"] == 96 * 96 * 64
+    assert two["rays_per_sample"] == one["rays_per_sample"], "same paths whatever the number of ranks"
+    assert two["config"]["collective"] == "gloo" and one["config"]["collective"] is None
+    for rec in (one, two):
+        assert "error" not in rec["e2e"], rec["e2e"]
+        assert rec["e2e"]["ppm_bytes"] > 96 * 96 * 6
+    assert two["e2e"]["gpus"] == 2 and one["e2e"]["gpus"] == 1

@@ -60,6 +60,14 @@ def test_unsupported_and_broken_files_fail_loudly(tmp_path):
     with pytest.raises(RuntimeError):
         host.load_image(str(bad))
     data[sof + 4] = 8
+    # non-integer chroma ratio: Y h=3 with Cb/Cr h=2 (the upsampler only knows whole ratios; ADVICE r1: was a heap over-read)
+    ratio = bytearray(data)
+    assert ratio[sof + 11] == 0x22 and ratio[sof + 14] == 0x11  # SOF: P, Y, X, Nf, then (id, hv, tq) per component
+    ratio[sof + 11], ratio[sof + 14], ratio[sof + 17] = 0x32, 0x21, 0x21
+    bad = tmp_path / "ratio_3_2.jpg"
+    bad.write_bytes(bytes(ratio))
+    with pytest.raises(RuntimeError):
+        host.load_image(str(bad))
     bad = tmp_path / "truncated_header.jpg"
     bad.write_bytes(bytes(data[:40]))
     with pytest.raises(RuntimeError):
