@@ -252,6 +252,19 @@ int rt_trace_batch(rt_ctx *ctx, const rt_scene *scene, const rt_ray *rays, const
 int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_params *params,
                      float *d_accum, void *stream, rt_stats *stats);
 
+/* rt_render_device for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for code that runs under
+ * HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same inputs, same output (d_accum), same
+ * kernels, asynchronous on `stream`; it calls no hipMalloc / hipFree.  What rt_render_device keeps in buffers it
+ * allocates -- the kernels' counters and the per-chunk partial frames -- lives in a file-scope __device__ array of
+ * 64 MiB that each GPU the library runs on holds until the process ends (4 KiB of counters + partial frames).
+ * Limits: image_width * image_height * 12 bytes <= 64 MiB - 4 KiB (5 592 064 pixels; 1920x1080 fits with two sample
+ * chunks), else RT_ERR_INVALID with a message; RT_PREC_F64 only after an allocating call has built the scene's f64 stream.
+ * The array is shared by every call on that GPU and keeps the last call's contents (the entry point clears what must
+ * start at zero): two calls that overlap on one GPU -- other streams, other contexts on the device -- race.  No stats:
+ * reading the ray counter back would synchronise. */
+int rt_render_static(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_params *params,
+                     float *d_accum, void *stream);
+
 /* write_color (color.h:20-45) on a summed buffer: out = int(256*clamp(sqrt(scale*sum),0,0.999)), NaN -> 0.
  * d_accum: device floats [n_pixels*3]; d_rgb8: device bytes [n_pixels*3]. */
 int rt_tonemap_device(rt_ctx *ctx, const float *d_accum, double scale, size_t n_pixels, uint8_t *d_rgb8,

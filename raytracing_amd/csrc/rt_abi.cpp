@@ -16,6 +16,17 @@
 
 using namespace rtamd;
 
+// ---- the scratch of rt_render_static (the entry point that allocates nothing) --------------------------------------------
+// Device memory beyond the caller's inputs and outputs that one render needs: the kernels' counters (ray count, work-item
+// cursor) and the per-chunk partial frames that reduce_chunks_kernel sums.  rt_render_device keeps both in hipMalloc'ed
+// buffers of the context; rt_render_static keeps them in this file-scope array: the counters in its first
+// RT_STATIC_COUNTER_BYTES, the partial frames behind them.  Every GPU the library runs on holds its own copy of the array
+// at its own address until the process ends.  In host code the NAME below is only a stand-in for hipGetSymbolAddress --
+// rt_init asks for the address once per context, with the context's device current -- and everything else (kernel
+// arguments, hipMemsetAsync) uses that pointer, never the name.
+enum : size_t { RT_STATIC_COUNTER_BYTES = 4096, RT_STATIC_SCRATCH_BYTES = (size_t)64 << 20 };
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
+
 struct rt_ctx {
     int device = 0;
     std::string err;
@@ -28,6 +39,7 @@ struct rt_ctx {
     uint8_t *rgb = nullptr;
     size_t rgb_bytes = 0;
     unsigned long long *counter = nullptr;
+    unsigned char *static_scratch = nullptr; // this device's copy of `scratch` (hipGetSymbolAddress in rt_init)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cus = 256;
     // development knobs (environment RT_AMD_LDS_UNITS / RT_AMD_CHUNKS); -1 / 0 = library default
@@ -367,6 +379,13 @@ int rt_init(int device, rt_ctx **out) {
         rt_shutdown(ctx);
         return RT_ERR_HIP;
     }
+    // this device's copy of the static scratch array (rt_render_static); the device is current here
+    e = hipGetSymbolAddress((void **)&ctx->static_scratch, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ctx->static_scratch) {
+        std::fprintf(stderr, "rt_init: hipGetSymbolAddress(scratch) on device %d: %s\n", device, hipGetErrorString(e));
+        rt_shutdown(ctx);
+        return RT_ERR_HIP;
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cus = prop.multiProcessorCount;
     if (const char *e1 = std::getenv("RT_AMD_LDS_UNITS")) ctx->lds_limit_units = std::atoi(e1);
@@ -495,6 +514,33 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
         return collect_stats(ctx, pl, ctx->counter, stats);
     }
     return RT_OK;
+}
+
+int rt_render_static(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_params *params, float *d_accum,
+                     void *stream_) {
+    if (!ctx || !scene || !cam || !params || !d_accum) return set_err(ctx, RT_ERR_INVALID, "rt_render_static: null argument");
+    if (scene->ctx != ctx) return set_err(ctx, RT_ERR_INVALID, "rt_render_static: the scene belongs to another context");
+    if (cam->image_width <= 0 || cam->image_height <= 0) return set_err(ctx, RT_ERR_INVALID, "render: bad camera");
+    // the partial frames live in the static array: that bounds the image
+    const size_t frame_bytes = (size_t)cam->image_width * (size_t)cam->image_height * 3 * sizeof(float);
+    const size_t room = RT_STATIC_SCRATCH_BYTES - RT_STATIC_COUNTER_BYTES;
+    if (frame_bytes > room)
+        return set_err(ctx, RT_ERR_INVALID,
+                       "rt_render_static: a " + std::to_string(cam->image_width) + " x " + std::to_string(cam->image_height) +
+                           " frame needs " + std::to_string(frame_bytes) + " bytes of scratch per sample chunk; the static scratch holds " +
+                           std::to_string(room) + " (at most " + std::to_string(room / (3 * sizeof(float))) +
+                           " pixels): use rt_render_device");
+    if (params->precision == RT_PREC_F64 && !scene->have_f64)
+        return set_err(ctx, RT_ERR_INVALID, "rt_render_static: the f64 stream of this scene is built (and allocated) by the first "
+                                            "RT_PREC_F64 call of rt_render_device / rt_trace_batch; make that call first");
+    RenderPlan pl;
+    int rc = plan_render(ctx, cam, params, (int)(room / frame_bytes), pl);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // every use of the array's memory goes through the per-device pointer taken in rt_init
+    unsigned long long *counters = reinterpret_cast<unsigned long long *>(ctx->static_scratch);
+    float *partial = reinterpret_cast<float *>(ctx->static_scratch + RT_STATIC_COUNTER_BYTES);
+    return enqueue_render(ctx, scene, cam, params->precision, pl, partial, counters, d_accum, (hipStream_t)stream_);
 }
 
 int rt_tonemap_device(rt_ctx *ctx, const float *d_accum, double scale, size_t n_pixels, uint8_t *d_rgb8, void *stream) {

@@ -1,7 +1,8 @@
 """ctypes binding of raytracing_amd/librt_amd.so (the C ABI of include/rt_amd.h).
 
 There is no CPU fallback: if the HIP library is missing or no GPU is present, loading / rt_init raises.
-torch is used by callers only for device buffers, streams and torch.distributed; this module itself needs numpy only.
+torch is used by callers only for device buffers, streams and torch.distributed; this module itself needs numpy only
+(it imports torch, when installed, before loading the library so that the process holds one HIP runtime: see load()).
 """
 from __future__ import annotations
 
@@ -17,7 +18,7 @@ LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")  
 
 EXPORTS = ["rt_abi_sizeof", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_upload", "rt_scene_free",
            "rt_scene_info", "rt_scene_flatten_info", "rt_trace_batch", "rt_render_device", "rt_tonemap_device", "rt_render",
-           "rt_render_multi"]
+           "rt_render_multi", "rt_render_static"]
 
 _lib = None
 
@@ -33,6 +34,14 @@ def load() -> C.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RtError(f"{LIB_PATH} not found: the HIP extension is not built (make -C raytracing_amd/csrc)")
+    # One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so (soname libamdhip64.so.7, the one librt_amd.so
+    # asks for); callers that hand this library torch device buffers need both to use the same copy.  The loader matches by
+    # soname only against what is ALREADY loaded, so torch comes first: loaded after librt_amd.so it would bring a second
+    # runtime into the process and find "No HIP GPUs".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.rt_abi_sizeof.restype = C.c_int
@@ -59,6 +68,8 @@ def load() -> C.CDLL:
     L.rt_tonemap_device.argtypes = [vp, vp, C.c_double, C.c_size_t, vp, vp]
     L.rt_render.restype = C.c_int
     L.rt_render.argtypes = [vp, vp, vp, C.POINTER(abi.RenderParams), vp, vp, C.POINTER(abi.Stats)]
+    L.rt_render_static.restype = C.c_int
+    L.rt_render_static.argtypes = [vp, vp, vp, C.POINTER(abi.RenderParams), vp, vp]
     L.rt_render_multi.restype = C.c_int
     L.rt_render_multi.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int, vp, C.POINTER(abi.RenderParams), vp, vp,
                                   C.POINTER(abi.Stats)]
@@ -174,6 +185,14 @@ class DeviceScene:
                                          C.byref(st) if want_stats else None)
         self.ctx.check(rc, "rt_render_device")
         return {"samples": st.samples, "rays": st.rays, "kernel_ms": st.kernel_ms} if want_stats else None
+
+    def render_static(self, camera: np.ndarray, d_accum_ptr: int, seed: int = 0, s_begin: int = 0,
+                      s_end: int = abi.RT_ALL_STRATA, precision: int = abi.RT_PREC_F32, sample_chunks: int = 0, stream: int = 0):
+        """rt_render_static: rt_render_device without any allocation (scratch in a static device array; size-limited)."""
+        cam = np.ascontiguousarray(camera, dtype=abi.camera_dtype).reshape(1)
+        p = abi.RenderParams(seed, s_begin, s_end, precision, sample_chunks)
+        rc = self.ctx.L.rt_render_static(self.ctx.h, self.h, cam.ctypes.data, C.byref(p), d_accum_ptr, stream or None)
+        self.ctx.check(rc, "rt_render_static")
 
     def tonemap_device(self, d_accum_ptr: int, scale: float, n_pixels: int, d_rgb_ptr: int, stream: int = 0):
         rc = self.ctx.L.rt_tonemap_device(self.ctx.h, d_accum_ptr, scale, n_pixels, d_rgb_ptr, stream or None)

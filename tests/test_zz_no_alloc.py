@@ -1,0 +1,108 @@
+"""GPU (-m gpu): rt_render_static, the entry point that allocates nothing (no counterpart in the reference; for callers
+under HIP graph capture, serving loops, harnesses that forbid hipMalloc).  Called through the C ABI; its output must equal
+rt_render_device's bit for bit (same kernels, same chunk schedule at these sizes) on two calls in a row, the second with a
+smaller input -- the static scratch keeps the first call's contents --, in both precisions; sizes beyond the static
+scratch are refused with a message; device memory in use does not change across the calls."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from raytracing_amd import abi, lib
+from tests import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_bytes():
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+@pytest.mark.parametrize("n", [3, 2])
+def test_static_entry_point_equals_render_device(gpu_ctx, n):
+    import torch
+    sc = fx.scene(n)
+    ds = gpu_ctx.upload(sc)
+    try:
+        cam0, _, _, _ = fx.img(n)  # 32 x 18
+        big = fx.with_size(sc.camera, sqrt_spp=5, max_depth=10)   # 64 x 36, 25 strata
+        small = fx.with_size(cam0, sqrt_spp=3, max_depth=6)       # 32 x 18, 9 strata: the second, smaller call
+        dev = torch.device("cuda", 0)
+        for prec in (abi.RT_PREC_F32, abi.RT_PREC_F64):
+            if prec == abi.RT_PREC_F64:
+                scratch_probe = torch.empty(32 * 18 * 3, dtype=torch.float32, device=dev)
+                with pytest.raises(lib.RtError, match="f64 stream"):  # nothing has built (allocated) the f64 stream yet
+                    ds.render_static(small, scratch_probe.data_ptr(), seed=3, precision=prec)
+            want = []
+            for cam in (big, small):
+                W, H = int(cam["image_width"][0]), int(cam["image_height"][0])
+                out = torch.full((H * W * 3,), -7.0, dtype=torch.float32, device=dev)
+                ds.render_device(cam, out.data_ptr(), seed=3, precision=prec)
+                torch.cuda.synchronize()
+                want.append(out.cpu().numpy())
+            outs = [torch.full((w.size,), -9.0, dtype=torch.float32, device=dev) for w in want]
+            warm = torch.empty(want[0].size, dtype=torch.float32, device=dev)
+            ds.render_static(big, warm.data_ptr(), seed=3, precision=prec)  # first use: the runtime may load code lazily
+            torch.cuda.synchronize()
+            before = _free_bytes()
+            ds.render_static(big, outs[0].data_ptr(), seed=3, precision=prec)
+            ds.render_static(small, outs[1].data_ptr(), seed=3, precision=prec)  # back to back on the same stream
+            torch.cuda.synchronize()
+            assert _free_bytes() == before, "rt_render_static must not allocate device memory"
+            for got, w in zip(outs, want):
+                g = got.cpu().numpy()
+                assert np.isfinite(w).any() and w.any()
+                assert g.tobytes() == w.tobytes(), f"precision {prec}: {int((g != w).sum())} of {w.size} values differ"
+            # a sub-range and forced chunking go the same way
+            a = torch.empty(want[0].size, dtype=torch.float32, device=dev)
+            b = torch.empty(want[0].size, dtype=torch.float32, device=dev)
+            ds.render_device(big, a.data_ptr(), seed=3, s_begin=4, s_end=21, precision=prec, sample_chunks=3)
+            ds.render_static(big, b.data_ptr(), seed=3, s_begin=4, s_end=21, precision=prec, sample_chunks=3)
+            torch.cuda.synchronize()
+            assert a.cpu().numpy().tobytes() == b.cpu().numpy().tobytes()
+            ds.render_static(big, b.data_ptr(), seed=3, s_begin=6, s_end=6, precision=prec)  # empty range: zeros
+            torch.cuda.synchronize()
+            assert not b.cpu().numpy().any()
+    finally:
+        ds.close()
+
+
+def test_static_entry_point_refuses_frames_beyond_its_scratch(gpu_ctx):
+    import torch
+    ds = gpu_ctx.upload(fx.scene(2))
+    try:
+        cam = fx.with_size(fx.scene(2).camera, sqrt_spp=2, max_depth=4)
+        cam["image_width"], cam["image_height"] = 4096, 2048  # 8.4 M pixels > 5 592 064
+        out = torch.empty(16, dtype=torch.float32, device="cuda:0")  # never written: the call is refused before any launch
+        with pytest.raises(lib.RtError, match="static scratch"):
+            ds.render_static(cam, out.data_ptr(), seed=1)
+        with pytest.raises(lib.RtError):
+            ds.render_static(cam, 0, seed=1)
+    finally:
+        ds.close()
+
+
+def test_static_entry_point_at_the_headline_size(gpu_ctx):
+    """1920 x 1080 fits (two partial frames): one eighth of the headline frame's strata, against rt_render_device."""
+    import torch
+    from raytracing_amd import scenes as scn
+    scene = scn.build("final_scene", 1920, 1080, 1000, 50)
+    ds = gpu_ctx.upload(scene)
+    try:
+        dev = torch.device("cuda", 0)
+        a = torch.empty(1920 * 1080 * 3, dtype=torch.float32, device=dev)
+        b = torch.empty(1920 * 1080 * 3, dtype=torch.float32, device=dev)
+        st = ds.render_device(scene.camera, a.data_ptr(), seed=11, s_begin=0, s_end=40, precision=abi.RT_PREC_F32, want_stats=True)
+        ds.render_static(scene.camera, b.data_ptr(), seed=11, s_begin=0, s_end=40, precision=abi.RT_PREC_F32)
+        torch.cuda.synchronize()
+        x, y = a.cpu().numpy(), b.cpu().numpy()
+        ok = np.isfinite(x)
+        assert st["samples"] == 1920 * 1080 * 40 and np.array_equal(ok, np.isfinite(y))
+        # different chunk schedules (2 partial frames against 3) and, at this size, a wave-schedule-dependent add order:
+        # the float sums agree to rounding
+        np.testing.assert_allclose(y[ok], x[ok], rtol=1e-5, atol=1e-4)
+    finally:
+        ds.close()
