@@ -392,7 +392,7 @@ static void on_render(camera &cam, const hittable &world, const hittable &lights
         return;
     }
 
-    if (g_mode == "trace") {
+    if (g_mode == "trace" || g_mode == "boxtrace") {
         std::map<const material *, int> prim_of_mat;
         set_unique_materials(f, prim_of_mat);
         std::vector<rt_ray> rays;
@@ -439,11 +439,70 @@ static void on_render(camera &cam, const hittable &world, const hittable &lights
             g_inject = false;
             return h;
         };
+        if (g_mode == "boxtrace") {
+            // batch C: rays through the corners, edges and faces of box() lists that stand in world space (final_scene's
+            // ground, cpuRenderer.cpp:298-312).  ray.time carries the class of the target: .1 corner, .2 edge midpoint
+            // (both exactly ON a line two or three faces share: equal-distance candidates), .3 face centre, .4 a point
+            // 1/1000 of the box's size inside a face next to an edge (no tie: the face must win).
+            rays.clear();
+            std::vector<int> boxes;
+            for (size_t id = 0; id < f.nodes.size(); id++) {
+                const rt_node &n = f.nodes[id];
+                if (n.kind != RT_NODE_LIST || n.b != 6) continue;
+                bool all_quads = true;
+                for (int k = 0; k < 6; k++) all_quads = all_quads && f.nodes[f.child_index[n.a + k]].kind == RT_NODE_QUAD;
+                if (all_quads) boxes.push_back((int)id);
+            }
+            const size_t step = boxes.size() > 64 ? boxes.size() / 64 : 1;
+            for (size_t bi = 0; bi < boxes.size(); bi += step) {
+                const rt_node &n = f.nodes[boxes[bi]];
+                double lo[3] = {infinity, infinity, infinity}, hi[3] = {-infinity, -infinity, -infinity};
+                for (int k = 0; k < 6; k++) {
+                    const rt_quad &q = f.quads[f.nodes[f.child_index[n.a + k]].a];
+                    for (int c = 0; c < 4; c++)
+                        for (int a = 0; a < 3; a++) {
+                            double x = q.Q[a] + ((c & 1) ? q.u[a] : 0.0) + ((c & 2) ? q.v[a] : 0.0);
+                            lo[a] = std::fmin(lo[a], x);
+                            hi[a] = std::fmax(hi[a], x);
+                        }
+                }
+                const double mid[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+                const double ext[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+                std::vector<std::pair<std::array<double, 3>, double>> targets;
+                for (int c = 0; c < 27; c++) { // every combination of {lo, mid, hi} per axis except the centre of the box
+                    const int s[3] = {c % 3, (c / 3) % 3, c / 9};
+                    const int n_mid = (s[0] == 1) + (s[1] == 1) + (s[2] == 1);
+                    if (n_mid == 3) continue;
+                    std::array<double, 3> p;
+                    for (int a = 0; a < 3; a++) p[a] = s[a] == 0 ? lo[a] : (s[a] == 1 ? mid[a] : hi[a]);
+                    targets.push_back({p, n_mid == 0 ? 0.1 : (n_mid == 1 ? 0.2 : 0.3)});
+                    if (n_mid == 1) { // an edge midpoint: also the two points just inside the faces that meet there
+                        for (int a = 0; a < 3; a++) {
+                            if (s[a] == 1) continue;
+                            std::array<double, 3> q = p; // move along axis a into the box: stays on the OTHER face
+                            q[a] += (s[a] == 0 ? 1.0 : -1.0) * 1e-3 * ext[a];
+                            targets.push_back({q, 0.4});
+                        }
+                    }
+                }
+                const point3 origins[2] = {cam.center, point3(mid[0] + 37.0, 700.0, mid[2] - 41.0)};
+                for (const point3 &o : origins)
+                    for (auto &t : targets) {
+                        rt_ray r{};
+                        Flat::put3(r.orig, o);
+                        for (int a = 0; a < 3; a++) r.dir[a] = (t.first[a] - r.orig[a]) * 0.37;
+                        r.time = t.second;
+                        rays.push_back(r);
+                    }
+            }
+            n_primary = rays.size();
+        }
         for (size_t k = 0; k < n_primary; k++) {
             double xi;
             hits.push_back(trace_one(rays[k], xi));
             xis.push_back(xi);
         }
+        if (g_mode == "boxtrace") g_nrays_extra = 0;
         // batch B: secondary-like rays leaving primary hit points in arbitrary directions (inside objects, grazing, ...)
         for (int k = 0; k < g_nrays_extra; k++) {
             const rt_hit &h0 = hits[lcg32() % n_primary];
@@ -559,7 +618,7 @@ int main(int argc, char **argv) {
     bool use_bvh = atoi(argv[7]) != 0;
     g_out = argv[8];
     if (argc > 9) {
-        if (g_mode == "trace") g_nrays_extra = atoi(argv[9]);
+        if (g_mode == "trace" || g_mode == "boxtrace") g_nrays_extra = atoi(argv[9]);
         else g_seed = (unsigned)atoi(argv[9]);
     }
     int frame = argc > 10 ? atoi(argv[10]) : 0;

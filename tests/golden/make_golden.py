@@ -281,6 +281,16 @@ def make_png():
     print("png fixtures:", ", ".join(expected))
 
 
+def make_boxtrace():
+    """final_scene's ground boxes (box() lists of six quads, quad.h:103) hit through their corners, edge midpoints, face
+    centres and points just inside a face next to an edge, from the camera and from above: the reference's quad ids /
+    normals / front_face for the rays the f32 stream answers from ONE fused slab test per box (refgen mode boxtrace)."""
+    refgen("boxtrace", 3, 64, 36, 9, 10, 1, f"{OUT}/boxtrace3.bin", 0)
+    rays, xi, hits = read_trace(f"{OUT}/boxtrace3.bin")
+    np.savez_compressed(f"{GOLD}/boxtrace3.npz", rays=rays.view("u1"), xi=xi, hits=hits.view("u1"))
+    print(f"boxtrace3: {len(rays)} rays, {(hits['prim'] >= 0).sum()} hits")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--converged", action="store_true", help="also (re)run the long converged renders")
@@ -288,6 +298,7 @@ def main():
     ap.add_argument("--anim-only", action="store_true", help="only (re)generate the animation fixtures")
     ap.add_argument("--jpeg-only", action="store_true", help="only (re)generate the JPEG decoding fixtures")
     ap.add_argument("--png-only", action="store_true", help="only (re)generate the PNG decoding fixtures")
+    ap.add_argument("--boxtrace-only", action="store_true", help="only (re)generate the box corner / edge ray batch")
     a = ap.parse_args()
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
     os.makedirs(OUT, exist_ok=True)
@@ -297,9 +308,13 @@ def main():
     if a.png_only:
         make_png()
         return
+    if a.boxtrace_only:
+        make_boxtrace()
+        return
     make_anim()
     if a.anim_only:
         return
+    make_boxtrace()
     # extra graph shapes: one frame of the bounce animation (cpuRenderer.cpp:19) and a scene without BVH
     refgen("dump", 5, 64, 36, 9, 10, 1, f"{OUT}/scene5_f7.rtscene", 0, 7)
     abi.Scene.load(f"{OUT}/scene5_f7.rtscene").save_npz(f"{GOLD}/scene5_f7.npz")

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from raytracing_amd import abi
+from tests import f32_bounds as fb
 from tests import fixtures as fx
 from tests import oracle_lib as O
 
@@ -39,31 +40,69 @@ def test_trace_batch_f64_matches_reference(scenes, n):
     assert np.isinf(got["t"][~hit]).all()
 
 
+def _check_f32_batch(name, sc, rays, xi, hits, got, min_same=0.99):
+    """Every ray of the batch, not a quantile: primitive ids equal except explained ties / grazing rays; t and normal within
+    1e-5 (north_star) or, where float cannot reach that, within the analytic bound of tests/f32_bounds.py -- and then the
+    ray is one the committed table tests/golden/f32_parity_table.json lists."""
+    rows = fb.classify(sc, rays, hits, got, xi)
+    unexplained = [r for r in rows if r["status"] == "unexplained"]
+    assert not unexplained, f"{len(unexplained)} unexplained primitive-id mismatches, e.g. {unexplained[:3]}"
+    same = [r for r in rows if r["status"] == "same"]
+    assert len(same) >= min_same * len(rows)
+    for r in same:
+        assert r["rel_t"] <= max(fb.BAR, r["bound_t"]), r
+        assert r["dn"] <= max(fb.BAR, r["bound_n"]), r
+        assert r["front_ok"] or r["cos"] <= 2e-3, r
+    table = fx.f32_table()[str(name)]
+    listed = {e["index"] for e in table["beyond_1e-5"]}
+    over = {r["index"] for r in same if r["rel_t"] > fb.BAR or r["dn"] > fb.BAR}
+    new = over - listed
+    # the table was written by the same kernels (tools/f32_parity_report.py); a change to the float arithmetic may move a
+    # few rays across 1e-5, a jump means the arithmetic got worse
+    assert len(new) <= max(2, len(listed) // 20), f"{len(new)} rays beyond 1e-5 that the committed table does not list: {sorted(new)[:10]}"
+    mism = {r["index"] for r in rows if r["status"] != "same"}
+    listed_m = {m["index"] for m in table["id_mismatches"]}
+    assert len(mism - listed_m) <= max(2, len(listed_m) // 4), sorted(mism - listed_m)[:10]
+    return rows
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 4])
 def test_trace_batch_f32_close_to_reference(scenes, n):
-    """Production arithmetic: ids may differ only on a handful of grazing rays; primary-ray t within 1e-5 relative."""
+    """Production arithmetic on ALL fixture rays (primary and secondary-like)."""
     rays, xi, hits = fx.trace(n)
     got = scenes[n].trace_batch(rays, xi, abi.RT_PREC_F32)
-    same = got["prim"] == hits["prim"]
-    # ids differ only (a) where two primitives are hit at the same distance -- the shared edge of two faces of a box: the
-    # same t to float precision, float rounding decides the winner (tools/trace_mismatch.py lists them) -- and (b) on a
-    # handful of rays that graze an edge or start on a surface
-    both = ~same & (got["prim"] >= 0) & (hits["prim"] >= 0)
-    with np.errstate(invalid="ignore"):  # inf - inf on rays that miss in both
-        tie = both & (np.abs(got["t"] - hits["t"]) <= 1e-5 * np.abs(hits["t"]))
-    assert (~same).sum() <= 0.005 * len(rays)
-    assert (~same & ~tie).sum() <= 0.002 * len(rays)
-    primary = np.arange(len(rays)) < 64 * 36
-    hit = same & (hits["prim"] >= 0) & primary
-    kinds = fx.scene(n).nodes["kind"][hits["prim"][hit]]
-    solid = kinds != abi.RT_NODE_MEDIUM  # a medium's t carries log(float(xi)): 1e-4 relative
-    rel_t = np.abs(got["t"][hit] - hits["t"][hit]) / np.abs(hits["t"][hit])
-    assert np.quantile(rel_t[solid], 0.99) <= 1e-5
-    assert rel_t[solid].max() <= 2e-4
-    if (~solid).any():
-        assert rel_t[~solid].max() <= 1e-3
-    dn = np.abs(got["normal"][hit] - hits["normal"][hit]).max(axis=1)
-    assert np.quantile(dn, 0.99) <= 1e-4
+    rows = _check_f32_batch(n, fx.scene(n), rays, xi, hits, got)
+    same = [r for r in rows if r["status"] == "same"]
+    print(f"scene {n}: {len(rows)} rays hit, {len(rows) - len(same)} id mismatches (all ties / grazing), "
+          f"{sum(r['rel_t'] > fb.BAR for r in same)} t and {sum(r['dn'] > fb.BAR for r in same)} normals beyond 1e-5, all within bound "
+          f"(worst measured/bound {max(r['rel_t'] / r['bound_t'] for r in same):.2f})")
+
+
+def test_box_corner_edge_batch(scenes):
+    """final_scene's ground boxes through their corners, edge midpoints, face centres and points next to an edge: the f64
+    stream (six quads per box) is bit-exact; the f32 stream answers from ONE fused slab test per box and must recover
+    the reference quad's id, normal and front_face -- exactly for the face-centre / next-to-edge classes, up to
+    equal-distance ties for the rays aimed exactly at a corner or an edge."""
+    rays, xi, hits = fx.boxtrace(3)
+    g64 = scenes[3].trace_batch(rays, xi, abi.RT_PREC_F64)
+    assert (g64["prim"] == hits["prim"]).all() and (g64["front_face"] == hits["front_face"]).all()
+    hit = hits["prim"] >= 0
+    solid = hit & (fx.scene(3).nodes["kind"][np.maximum(hits["prim"], 0)] != abi.RT_NODE_MEDIUM)
+    assert np.abs(g64["t"][solid] - hits["t"][solid]).max() == 0 and np.abs(g64["normal"][hit] - hits["normal"][hit]).max() == 0
+    assert (np.abs(g64["t"][hit] - hits["t"][hit]) / hits["t"][hit]).max() <= 1e-12  # a medium's t carries the device's log()
+    got = scenes[3].trace_batch(rays, xi, abi.RT_PREC_F32)
+    # (a third of the batch is aimed exactly at corners and edges: equal-distance candidates by construction)
+    rows = _check_f32_batch("box3", fx.scene(3), rays, xi, hits, got, min_same=0.9)
+    by_index = {r["index"]: r for r in rows}
+    cls = np.round(rays["time"] * 10).astype(int)
+    for c, label in ((3, "face centre"), (4, "next to an edge")):
+        idx = np.nonzero(cls == c)[0]
+        bad = [k for k in idx if k in by_index and by_index[k]["status"] != "same"]
+        # a ray aimed into one box's face can still pass exactly through an edge of a box in front of it (the camera sits
+        # in a plane the box lattice shares: the explanation of every such ray reads "accepted with margin 0")
+        assert len(bad) <= 0.005 * len(idx) + 1, (label, bad[:10])
+    on_quads = [r for r in rows if r["status"] == "same" and r["kind"] == abi.RT_NODE_QUAD]
+    assert len(on_quads) > 5000 and all(r["dn"] <= 1e-6 and r["front_ok"] for r in on_quads)
 
 
 def test_trace_batch_keyed_medium_rng_matches_oracle(scenes):

@@ -24,6 +24,37 @@ def test_trace_batch_bit_exact(n):
     assert (hits["prim"] >= 0).sum() > 1000
 
 
+def test_box_corner_edge_batch_bit_exact():
+    """final_scene's ground boxes hit exactly through corners and edges (equal-distance candidates: the winner is decided
+    by the reference's visiting order and its strict / inclusive interval tests) and next to them."""
+    sc = fx.scene(3)
+    rays, xi, hits = fx.boxtrace(3)
+    got, _ = O.trace_batch(sc, rays, xi)
+    assert (got["prim"] == hits["prim"]).all()
+    for f in ("t", "p", "normal", "u", "v", "front_face"):
+        assert _bytes_equal(got[f], hits[f]), f
+    assert len(rays) == 6700 and (hits["prim"] >= 0).sum() > 6000
+
+
+def test_f32_bounds_module_agrees_with_the_reference_hits():
+    """tests/f32_bounds.py re-derives acceptance margins in double precision: on the reference's own hits it must accept
+    the reference's primitive at the reference's distance (otherwise its 'explanations' of float mismatches mean nothing)."""
+    import math
+    from tests import f32_bounds as fb
+    for n in (1, 2, 3, 4):
+        sc = fx.scene(n)
+        rays, xi, hits = fx.trace(n)
+        chains = fb.transform_chains(sc)
+        idx = np.nonzero(hits["prim"] >= 0)[0][::5]
+        for k in idx:
+            r = int(hits["prim"][k])
+            ok, t, m = fb.margin(sc, r, chains[r], rays[k], math.inf, float(xi[k]))
+            assert ok and m >= 0, (n, k)
+            assert abs(t - hits["t"][k]) <= 2e-7 * abs(hits["t"][k]), (n, k)  # triangles: the reference rounds t to float
+        rows = fb.classify(sc, rays, hits, hits, xi)
+        assert all(r["status"] == "same" and r["rel_t"] == 0 and r["dn"] == 0 for r in rows)
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 4])
 def test_whole_frame_bit_exact(n):
     sc = fx.scene(n)
