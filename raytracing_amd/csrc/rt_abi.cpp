@@ -1,6 +1,7 @@
 // rt_abi.cpp -- implementation of the C ABI declared in include/rt_amd.h (host side, HIP runtime API).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -126,7 +127,13 @@ struct BlobBuilder {
     }
 };
 
+double wall_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, DeviceScene<R> &ds) {
+    const bool timing = std::getenv("RT_AMD_TIMING") != nullptr; // development aid: where an upload's time goes
+    const double t0 = wall_ms();
     Flat<R> f;
     std::string err;
     Flattener<R> fl(*desc, f, err, /*fuse_boxes=*/sizeof(R) == 4);
@@ -141,8 +148,13 @@ template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, Device
     b.host.resize((b.host.size() + 255) & ~size_t(255));
     const size_t tab_bytes = b.host.size() - o_xf;
     ds.bytes = b.host.size();
+    const double t1 = wall_ms();
     HIP_TRY(ctx, hipMalloc(&ds.blob, ds.bytes));
+    const double t2 = wall_ms();
     HIP_TRY(ctx, hipMemcpy(ds.blob, b.host.data(), ds.bytes, hipMemcpyHostToDevice));
+    if (timing)
+        std::fprintf(stderr, "[rt_amd timing] upload<%s>: flatten + blob %.2f ms, hipMalloc %.2f ms, hipMemcpy of %zu bytes %.2f ms\n",
+                     sizeof(R) == 4 ? "f32" : "f64", t1 - t0, t2 - t1, ds.bytes, wall_ms() - t2);
     uint8_t *base = (uint8_t *)ds.blob;
     SceneT<R> &s = ds.sc;
     s.stream = (const UnitT<R> *)(base + o_stream);
@@ -378,6 +390,16 @@ int rt_init(int device, rt_ctx **out) {
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         rt_shutdown(ctx);
         return RT_ERR_HIP;
+    }
+    // The runtime sets up its host-to-device copy path (staging buffers, blit kernels) on the FIRST copy of the process:
+    // 15 ms, 150 ms in the first process on a freshly booted box.  Paid here, with the other one-off costs of creating a
+    // context, instead of inside the first frame's scene upload.
+    {
+        const unsigned long long zeros[40] = {};
+        if (hipMemcpy(ctx->counter, zeros, sizeof(zeros), hipMemcpyHostToDevice) != hipSuccess) {
+            rt_shutdown(ctx);
+            return RT_ERR_HIP;
+        }
     }
     // this device's copy of the static scratch array (rt_render_static); the device is current here
     e = hipGetSymbolAddress((void **)&ctx->static_scratch, HIP_SYMBOL(scratch));
