@@ -257,8 +257,9 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
  * kernels, asynchronous on `stream`; it calls no hipMalloc / hipFree.  What rt_render_device keeps in buffers it
  * allocates -- the kernels' counters and the per-chunk partial frames -- lives in a file-scope __device__ array of
  * 64 MiB that each GPU the library runs on holds until the process ends (4 KiB of counters + partial frames).
- * Limits: image_width * image_height * 12 bytes <= 64 MiB - 4 KiB (5 592 064 pixels; 1920x1080 fits with two sample
- * chunks), else RT_ERR_INVALID with a message; RT_PREC_F64 only after an allocating call has built the scene's f64 stream.
+ * Limits: one partial frame must fit, image_width * image_height * 3 cells <= 64 MiB - 4 KiB with 8-byte cells at
+ * RT_PREC_F32 (2 796 032 pixels: 1920x1080 fits, as a single sample chunk) and 4-byte cells at RT_PREC_F64 (5 592 064
+ * pixels), else RT_ERR_INVALID with a message; RT_PREC_F64 only after an allocating call has built the scene's f64 stream.
  * The array is shared by every call on that GPU and keeps the last call's contents (the entry point clears what must
  * start at zero): two calls that overlap on one GPU -- other streams, other contexts on the device -- race.  No stats:
  * reading the ray counter back would synchronise. */

@@ -31,7 +31,7 @@ static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
 struct rt_ctx {
     int device = 0;
     std::string err;
-    float *partial = nullptr; // per-chunk accumulation buffers [n_chunks][H][W][3]
+    void *partial = nullptr; // per-chunk partial frames [n_chunks][H][W][3]: 64-bit fixed-point cells (f32) or floats (f64)
     size_t partial_bytes = 0;
     float *accum = nullptr; // used by the host-buffer convenience entry points rt_render / rt_render_multi
     size_t accum_bytes = 0;
@@ -294,21 +294,25 @@ int plan_render(rt_ctx *ctx, const rt_camera *cam, const rt_render_params *param
 // Enqueue one planned render on `stream` of the context's device (current on entry): counters cleared, the path-tracing
 // kernel into `partial` (n_chunks > 1) or straight into d_accum, then the fixed-order sum of the partial frames.  Nothing
 // here allocates or synchronises.
-int enqueue_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, int precision, const RenderPlan &pl, float *partial,
+size_t partial_cell_bytes(int precision) { return precision == RT_PREC_F32 ? 8 : 4; }
+
+int enqueue_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, int precision, const RenderPlan &pl_, void *partial,
                    unsigned long long *counters, float *d_accum, hipStream_t stream) {
+    RenderPlan pl = pl_;
+    pl.rl.out_i64 = (precision == RT_PREC_F32 && pl.n_chunks > 1) ? 1 : 0;
     if (pl.n_samples == 0) {
         HIP_TRY(ctx, hipMemsetAsync(d_accum, 0, pl.n_px * 3 * sizeof(float), stream));
         HIP_TRY(ctx, hipMemsetAsync(counters, 0, 40 * sizeof(unsigned long long), stream));
         return RT_OK;
     }
-    float *target = pl.n_chunks > 1 ? partial : d_accum;
+    void *target = pl.n_chunks > 1 ? partial : (void *)d_accum;
     HIP_TRY(ctx, hipMemsetAsync(counters, 0, 40 * sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipMemsetAsync(counters + 37, 0xff, sizeof(unsigned long long), stream)); // [37]: a minimum (diagnostic builds)
     if (precision == RT_PREC_F64)
         HIP_TRY(ctx, launch_render<double>(scene->f64.sc, convert_camera<double>(*cam), pl.rl, target, counters, stream));
     else
         HIP_TRY(ctx, launch_render<float>(scene->f32.sc, convert_camera<float>(*cam), pl.rl, target, counters, stream));
-    if (pl.n_chunks > 1) HIP_TRY(ctx, launch_reduce_chunks(partial, d_accum, pl.n_px * 3, pl.n_chunks, stream));
+    if (pl.n_chunks > 1) HIP_TRY(ctx, launch_reduce_chunks(partial, pl.rl.out_i64 != 0, d_accum, pl.n_px * 3, pl.n_chunks, stream));
     return RT_OK;
 }
 
@@ -525,7 +529,7 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (params->precision == RT_PREC_F64 && (rc = need_f64(ctx, scene)) != RT_OK) return rc;
     if (pl.n_chunks > 1) {
-        rc = ensure(ctx, (void **)&ctx->partial, &ctx->partial_bytes, (size_t)pl.n_chunks * pl.n_px * 3 * sizeof(float));
+        rc = ensure(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)pl.n_chunks * pl.n_px * 3 * partial_cell_bytes(params->precision));
         if (rc) return rc;
     }
     if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
@@ -544,14 +548,15 @@ int rt_render_static(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
     if (scene->ctx != ctx) return set_err(ctx, RT_ERR_INVALID, "rt_render_static: the scene belongs to another context");
     if (cam->image_width <= 0 || cam->image_height <= 0) return set_err(ctx, RT_ERR_INVALID, "render: bad camera");
     // the partial frames live in the static array: that bounds the image
-    const size_t frame_bytes = (size_t)cam->image_width * (size_t)cam->image_height * 3 * sizeof(float);
+    const int prec_ok = params->precision == RT_PREC_F64 ? RT_PREC_F64 : RT_PREC_F32;
+    const size_t frame_bytes = (size_t)cam->image_width * (size_t)cam->image_height * 3 * partial_cell_bytes(prec_ok);
     const size_t room = RT_STATIC_SCRATCH_BYTES - RT_STATIC_COUNTER_BYTES;
     if (frame_bytes > room)
         return set_err(ctx, RT_ERR_INVALID,
                        "rt_render_static: a " + std::to_string(cam->image_width) + " x " + std::to_string(cam->image_height) +
                            " frame needs " + std::to_string(frame_bytes) + " bytes of scratch per sample chunk; the static scratch holds " +
-                           std::to_string(room) + " (at most " + std::to_string(room / (3 * sizeof(float))) +
-                           " pixels): use rt_render_device");
+                           std::to_string(room) + " (at most " + std::to_string(room / (3 * partial_cell_bytes(prec_ok))) +
+                           " pixels at this precision): use rt_render_device");
     if (params->precision == RT_PREC_F64 && !scene->have_f64)
         return set_err(ctx, RT_ERR_INVALID, "rt_render_static: the f64 stream of this scene is built (and allocated) by the first "
                                             "RT_PREC_F64 call of rt_render_device / rt_trace_batch; make that call first");
@@ -561,7 +566,7 @@ int rt_render_static(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // every use of the array's memory goes through the per-device pointer taken in rt_init
     unsigned long long *counters = reinterpret_cast<unsigned long long *>(ctx->static_scratch);
-    float *partial = reinterpret_cast<float *>(ctx->static_scratch + RT_STATIC_COUNTER_BYTES);
+    void *partial = ctx->static_scratch + RT_STATIC_COUNTER_BYTES;
     return enqueue_render(ctx, scene, cam, params->precision, pl, partial, counters, d_accum, (hipStream_t)stream_);
 }
 
@@ -638,7 +643,7 @@ int rt_render_multi(rt_ctx *const *ctxs, const rt_scene *const *scenes, int n_de
         if (params->precision == RT_PREC_F64 && (rc = need_f64(c, scenes[k])) != RT_OK) return fail_from(k, rc);
         if ((rc = ensure(c, (void **)&c->accum, &c->accum_bytes, bytes)) != RT_OK) return fail_from(k, rc);
         if (plans[k].n_chunks > 1 &&
-            (rc = ensure(c, (void **)&c->partial, &c->partial_bytes, (size_t)plans[k].n_chunks * bytes)) != RT_OK)
+            (rc = ensure(c, &c->partial, &c->partial_bytes, (size_t)plans[k].n_chunks * n_px * 3 * partial_cell_bytes(params->precision))) != RT_OK)
             return fail_from(k, rc);
         if (hipEventRecord(c->ev0, nullptr) != hipSuccess) return fail_from(k, set_err(c, RT_ERR_HIP, "hipEventRecord failed"));
         if ((rc = enqueue_render(c, scenes[k], cam, params->precision, plans[k], c->partial, c->counter, c->accum, nullptr)) != RT_OK)

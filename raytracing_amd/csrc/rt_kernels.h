@@ -1051,8 +1051,31 @@ RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SC &sc, const CameraT<R> &ca
     return true;
 }
 
-// LDS accumulation of a finished path (ds_add_f32 / ds_add_f64; wave scope: only this wave touches its accumulators)
-template <class R> RT_DEV void lds_add(R *p, R v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+// LDS accumulation of a finished path (wave scope: only this wave touches its accumulators).
+//   double kernels: ds_add_f64 on double cells (rounding ~1e-16: the float result practically never depends on the order).
+//   float kernels : 64-bit FIXED-POINT cells, ds_add_u64.  Integer adds commute, so a pixel's sum does not depend on
+//   which wave picked the item up or on the order in which the wave's lanes finish their paths: frames repeat bit for
+//   bit, and a frame equals the sum of its stratum ranges up to the final conversion to float.  Unit 2^-24 (6e-8); a
+//   sample is clamped to [0, 2^20] first -- a sample above sqrt_spp^2 saturates its pixel to 255 by itself whatever else
+//   is added (write_color clamps at 0.999), so the 8-bit image is the reference's for up to 2^20 samples per pixel --
+//   and a NaN sample (which makes the reference's pixel NaN, i.e. black: color.h:26-28) sets the cell's NaN flag.
+enum : int { RT_FX_SHIFT = 24 };
+#define RT_FX_CLAMP 1048576.0f
+struct I64Out { // what a float kernel stores per cell when several sample chunks are summed afterwards
+    static constexpr long long nan_cell = 0x7fffffffffffffffll;
+};
+template <class R> struct CellOf { using T = double; };
+template <> struct CellOf<float> { using T = unsigned long long; };
+RT_DEV void lds_add(double *p, double v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+RT_DEV void lds_add(unsigned long long *p, unsigned long long v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+RT_DEV unsigned long long to_fixed(float v) { // v in [0, 2^20], exact: a float has 24 significant bits
+    const float f = v * 16777216.0f;                                   // v * 2^24 < 2^45
+    const unsigned hi = (unsigned)(f * 2.3283064365386963e-10f);       // floor(f / 2^32)
+    const unsigned lo = (unsigned)(fmaf(-(float)hi, 4294967296.0f, f) + 0.5f); // the remainder, rounded to nearest
+    return ((unsigned long long)hi << 32) + lo;
+}
 
 // Wave-uniform helpers that stay on the scalar unit: the lane mask of a predicate without the int round trip of
 // __ballot(), and its population count as two 32-bit s_bcnt1 (a 64-bit count is compared on the VALU).
@@ -1098,6 +1121,7 @@ struct RenderArgs {
     int32_t chunk_size;      // > 0: equal chunks of this many samples; 0: the boundaries in chunk_start[]
     int32_t tiles_x, tiles_y;
     int32_t n_chunks;
+    int32_t out_i64;         // float kernels: `out` receives 64-bit fixed-point cells (chunks summed afterwards), else floats
     int32_t chunk_start[RT_MAX_SCHED_CHUNKS + 1];        // decreasing-size schedule (chunk c = [chunk_start[c], chunk_start[c+1]))
 };
 enum : int { A_BOX = 0, A_SPHERE = 1, A_AABOX = 2, A_MEDIUM = 3, A_OTHER = 4, A_SHADE = 5, A_COUNT = 6, A_DEAL = 7 };
@@ -1111,11 +1135,14 @@ enum : int { A_BOX = 0, A_SPHERE = 1, A_AABOX = 2, A_MEDIUM = 3, A_OTHER = 4, A_
 // per-wave item state (LdsLayout::state_ints ints behind the wave's accumulators):
 // slot k: ws[4k .. 4k+3] = tile origin i0, j0, chunk, valid; then the dealing item's slot, first sample and unit count
 enum : int { WS_SLOT_I0 = 0, WS_SLOT_J0 = 1, WS_SLOT_CHUNK = 2, WS_SLOT_VALID = 3, WS_CUR_SLOT = 4 * RT_ITEM_SLOTS, WS_CUR_S0 = 4 * RT_ITEM_SLOTS + 1,
-              WS_N_UNITS = 4 * RT_ITEM_SLOTS + 2 };
+              WS_N_UNITS = 4 * RT_ITEM_SLOTS + 2, WS_NAN = 4 * RT_ITEM_SLOTS + 16 /* nan_words ints per slot */ };
 
 template <class R, bool ALL_LDS, bool TAB_LDS, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT<R> cam_arg, RenderArgs a_arg, float *__restrict__ out,
+__global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT<R> cam_arg, RenderArgs a_arg, void *__restrict__ out_,
                                                        unsigned long long *__restrict__ counters) {
+    using Cell = typename CellOf<R>::T;
+    float *const out = reinterpret_cast<float *>(out_);
+    long long *const out64 = reinterpret_cast<long long *>(out_);
     static_assert(BLOCK == LdsLayout<R>::block, "LDS layout");
     // Kernel arguments arrive as 8- and 16-dword scalar loads; left alone, the register allocator spills and reloads such a
     // tuple WHOLE (16 v_readlane for one pointer).  Passing every field through an empty asm makes each its own value.
@@ -1135,7 +1162,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     const int lane = threadIdx.x & 63;
     const R tmin = R(0.001);
     // this wave's accumulators (item_slots slots = items in flight, x tile_px pixels x RGB) and item state
-    R *const acc = reinterpret_cast<R *>(rt_smem + LdsLayout<R>::wave_off + (threadIdx.x >> 6) * LdsLayout<R>::wave_stride);
+    Cell *const acc = reinterpret_cast<Cell *>(rt_smem + LdsLayout<R>::wave_off + (threadIdx.x >> 6) * LdsLayout<R>::wave_stride);
     int *const ws = reinterpret_cast<int *>(acc + LdsLayout<R>::wave_acc);
     unsigned rays = 0;
 #ifdef RT_PROFILE_TAIL
@@ -1157,7 +1184,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     // from run to run only to rounding once a wave handles several items).
     constexpr int NS = LdsLayout<R>::item_slots;
     constexpr int TPX = LdsLayout<R>::tile_px, TSH = LdsLayout<R>::tile_shift; // pixels per item, log2 of it
-    for (int k = lane; k < LdsLayout<R>::wave_acc; k += 64) acc[k] = R(0);
+    for (int k = lane; k < LdsLayout<R>::wave_acc; k += 64) acc[k] = Cell(0);
     for (int k = lane; k < LdsLayout<R>::state_ints; k += 64) ws[k] = 0;
     RayT<R> ray;
     V3<R> beta;
@@ -1174,13 +1201,28 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     // every path of an item has ended: lane p stores pixel p's sums and clears the accumulator for its next item
     auto flush = [&](int slot, int i0, int j0, int chunk) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        R *const b = acc + slot * LdsLayout<R>::slot_acc + (lane & (TPX - 1)) * 3;
-        const int i = i0 + (lane & 7), j = j0 + (lane >> 3);
+        const int cell0 = (lane & (TPX - 1)) * 3;
+        Cell *const b = acc + slot * LdsLayout<R>::slot_acc + cell0;
+        const int i = i0 + (lane & 7), j = j0 + ((lane & (TPX - 1)) >> 3);
         if (lane < TPX && i < cam.W && j < cam.H) {
             const size_t o = ((size_t)chunk * cam.H * cam.W + (size_t)j * cam.W + i) * 3;
-            out[o] = (float)b[0]; out[o + 1] = (float)b[1]; out[o + 2] = (float)b[2];
+            if constexpr (sizeof(R) == 4) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const int bit = cell0 + c;
+                    const bool nan = (ws[WS_NAN + slot * LdsLayout<R>::nan_words + (bit >> 5)] >> (bit & 31)) & 1;
+                    if (a.out_i64) out64[o + c] = nan ? I64Out::nan_cell : (long long)b[c];
+                    else out[o + c] = nan ? __builtin_nanf("") : (float)((double)b[c] * (1.0 / 16777216.0));
+                }
+            } else {
+                out[o] = (float)b[0]; out[o + 1] = (float)b[1]; out[o + 2] = (float)b[2];
+            }
         }
-        if (lane < TPX) { b[0] = R(0); b[1] = R(0); b[2] = R(0); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the NaN words are read above by all lanes, cleared below by some
+        if (lane < TPX) { b[0] = Cell(0); b[1] = Cell(0); b[2] = Cell(0); }
+        if constexpr (sizeof(R) == 4) {
+            if (lane < LdsLayout<R>::nan_words) ws[WS_NAN + slot * LdsLayout<R>::nan_words + lane] = 0;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     };
 
@@ -1303,8 +1345,30 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         rays++;
                         trav_begin(mem, tv, ray);
                     } else {
-                        R *const px = acc + pp * 3;
-                        lds_add(px, L.x); lds_add(px + 1, L.y); lds_add(px + 2, L.z);
+                        Cell *const px = acc + pp * 3;
+                        if constexpr (sizeof(R) == 4) {
+                            const float lv[3] = {L.x, L.y, L.z};
+                            // the usual sample: three finite values in [0, 256) -> v * 2^24 fits 32 bits, one fma + one
+                            // conversion per channel.  (Which branch a sample takes depends on the sample alone.)
+                            const float sum = (L.x + L.y) + L.z; // NaN if any channel is
+                            if (sum < 256.0f && fminf(fminf(L.x, L.y), L.z) >= 0.0f) {
+#pragma unroll
+                                for (int c = 0; c < 3; c++) lds_add(px + c, (unsigned long long)(unsigned)fmaf(lv[c], 16777216.0f, 0.5f));
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < 3; c++) {
+                                    if (lv[c] != lv[c]) { // NaN: flag the cell (0/0 weights, a light sphere seen from inside)
+                                        const int bit = (pp & (TPX - 1)) * 3 + c;
+                                        (void)__hip_atomic_fetch_or(&ws[WS_NAN + (pp >> TSH) * LdsLayout<R>::nan_words + (bit >> 5)], 1 << (bit & 31),
+                                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                    } else {
+                                        lds_add(px + c, to_fixed(__builtin_amdgcn_fmed3f(lv[c], 0.0f, RT_FX_CLAMP)));
+                                    }
+                                }
+                            }
+                        } else {
+                            lds_add(px, L.x); lds_add(px + 1, L.y); lds_add(px + 2, L.z);
+                        }
                         tv.hdr = K_IDLE; // asks for its next unit at the top of the loop
                     }
                 }

@@ -30,14 +30,31 @@ __global__ void add_into_kernel(float *__restrict__ dst, const float *__restrict
     if (k < n) dst[k] += src[k];
 }
 
-template hipError_t launch_render<float>(const SceneT<float> &, const CameraT<float> &, const RenderLaunch &, float *,
+// The float kernels' partial frames: 64-bit fixed-point cells (unit 2^-24), summed exactly; a NaN-flagged cell in any chunk
+// makes the pixel NaN, as one NaN sample does in the reference's sum.
+__global__ void reduce_chunks_i64_kernel(const long long *__restrict__ partial, float *__restrict__ out, size_t n, int n_chunks) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    long long s = 0;
+    bool nan = false;
+    for (int c = 0; c < n_chunks; c++) {
+        const long long v = partial[(size_t)c * n + k];
+        nan = nan || v == I64Out::nan_cell;
+        s += v;
+    }
+    out[k] = nan ? __builtin_nanf("") : (float)((double)s * (1.0 / 16777216.0));
+}
+
+template hipError_t launch_render<float>(const SceneT<float> &, const CameraT<float> &, const RenderLaunch &, void *,
                                          unsigned long long *, hipStream_t);
 template hipError_t launch_trace<float>(const SceneT<float> &, const rt_ray *, const double *, size_t, rt_hit *, uint32_t,
                                         uint32_t, int, hipStream_t);
 
-hipError_t launch_reduce_chunks(const float *partial, float *out, size_t n, int n_chunks, hipStream_t stream) {
+hipError_t launch_reduce_chunks(const void *partial, bool cells_i64, float *out, size_t n, int n_chunks, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, out, n, n_chunks);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (cells_i64) hipLaunchKernelGGL(reduce_chunks_i64_kernel, grid, block, 0, stream, (const long long *)partial, out, n, n_chunks);
+    else hipLaunchKernelGGL(reduce_chunks_kernel, grid, block, 0, stream, (const float *)partial, out, n, n_chunks);
     return hipGetLastError();
 }
 

@@ -4,7 +4,7 @@
 
 namespace rtamd {
 
-template hipError_t launch_render<double>(const SceneT<double> &, const CameraT<double> &, const RenderLaunch &, float *,
+template hipError_t launch_render<double>(const SceneT<double> &, const CameraT<double> &, const RenderLaunch &, void *,
                                           unsigned long long *, hipStream_t);
 template hipError_t launch_trace<double>(const SceneT<double> &, const rt_ray *, const double *, size_t, rt_hit *, uint32_t,
                                          uint32_t, int, hipStream_t);

@@ -12,6 +12,7 @@ enum : int { RT_MAX_SCHED_CHUNKS_HOST = 24 }; // == RT_MAX_SCHED_CHUNKS of rt_ke
 struct RenderLaunch {
     uint32_t k0, k1;
     int32_t s_begin, s_end, chunk_size, n_chunks;
+    int32_t out_i64; // float kernels only: store 64-bit fixed-point cells (the per-chunk partial frames), not floats
     int32_t chunk_start[25]; // used when chunk_size == 0 (n_chunks <= 24)
     int32_t n_cus;
 };
@@ -28,12 +29,14 @@ template <class R> struct LaunchCfg {
 
 // counters: device pointer to two 64-bit words, both zero at launch: [0] rays traced (out), [1] work-item cursor
 template <class R>
-hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const RenderLaunch &rl, float *out,
+hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const RenderLaunch &rl, void *out,
                          unsigned long long *counters, hipStream_t stream);
 template <class R>
 hipError_t launch_trace(const SceneT<R> &sc, const rt_ray *d_rays, const double *d_xi, size_t n, rt_hit *d_out,
                         uint32_t k0, uint32_t k1, int n_cus, hipStream_t stream);
-hipError_t launch_reduce_chunks(const float *partial, float *out, size_t n, int n_chunks, hipStream_t stream);
+// partial frames -> the caller's float sums.  cells_i64: the partial frames are the float kernels' 64-bit fixed-point cells
+// (summed exactly, so the result does not depend on how the samples were cut into chunks), else floats (double kernels).
+hipError_t launch_reduce_chunks(const void *partial, bool cells_i64, float *out, size_t n, int n_chunks, hipStream_t stream);
 hipError_t launch_tonemap(const float *accum, double scale, size_t n, uint8_t *rgb, hipStream_t stream);
 hipError_t launch_add_into(float *dst, const float *src, size_t n, hipStream_t stream); // dst[k] += src[k]
 

@@ -13,7 +13,7 @@ template <class K> hipError_t allow_lds(K kernel, int bytes) {
 }
 
 template <class R>
-hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const RenderLaunch &rl, float *out,
+hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const RenderLaunch &rl, void *out,
                          unsigned long long *counters, hipStream_t stream) {
     using C = LaunchCfg<R>;
     RenderArgs a;
@@ -23,6 +23,7 @@ hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const Rende
     a.s_end = rl.s_end;
     a.chunk_size = rl.chunk_size;
     a.n_chunks = rl.n_chunks;
+    a.out_i64 = sizeof(R) == 4 ? rl.out_i64 : 0;
     for (int k = 0; k <= RT_MAX_SCHED_CHUNKS; k++) a.chunk_start[k] = rl.chunk_start[k];
     if (rl.chunk_size == 0 && (rl.n_chunks < 1 || rl.n_chunks > RT_MAX_SCHED_CHUNKS)) return hipErrorInvalidValue;
     a.tiles_x = (cam.W + 7) / 8;

@@ -190,14 +190,16 @@ template <class R> struct SceneT { // device pointers; passed to kernels by valu
 };
 
 // LDS map of a workgroup (all offsets are compile-time constants, so no register holds them):
-//   [0, stream_off)            per wave: item_slots accumulator slots (items in flight) x tile_px pixels x RGB, then the
-//                              wave's item state (4 ints per slot + 16)
+//   [0, stream_off)            per wave: item_slots accumulator slots (items in flight) x tile_px pixels x RGB cells of 8
+//                              bytes (f32 kernels: 64-bit fixed point, so that a pixel's sum does not depend on the order
+//                              of the adds; f64 kernels: double), then the wave's item state (4 ints per slot + 16 + the
+//                              slots' NaN flags)
 //   [stream_off, ...)          the leading lds_units units of the record stream, then (when they fit) the shading tables
 #ifndef RT_ITEM_SLOTS
 #define RT_ITEM_SLOTS 16
 #endif
-#ifndef RT_TILE_H // an item's pixel tile is 8 wide and RT_TILE_H (8, 4 or 2) high
-#define RT_TILE_H 2
+#ifndef RT_TILE_H // an item's pixel tile is 8 wide and RT_TILE_H (8, 4, 2 or 1) high
+#define RT_TILE_H 1
 #endif
 #ifndef RT_F32_BLOCK
 #define RT_F32_BLOCK 1024
@@ -206,12 +208,14 @@ template <class R> struct LdsLayout {
     static constexpr int block = sizeof(R) == 4 ? RT_F32_BLOCK : 512; // f32: 16 waves/CU, <= 128 VGPRs; f64 (parity path): 8 waves
     static constexpr int waves = block / 64;
     static constexpr int item_slots = RT_ITEM_SLOTS;                           // items in flight per wave
-    static constexpr int tile_h = RT_TILE_H, tile_px = 8 * tile_h, tile_shift = tile_h == 8 ? 6 : tile_h == 4 ? 5 : 4;
-    static constexpr int slot_acc = tile_px * 3;                               // accumulator scalars per slot
-    static constexpr int wave_acc = item_slots * slot_acc;                     // accumulator scalars per wave
-    static constexpr int state_ints = 4 * item_slots + 16;                     // per slot: i0, j0, chunk, valid; then the current item
-    static constexpr int wave_stride = wave_acc * (int)sizeof(R) + state_ints * 4; // bytes per wave
-    static_assert((tile_h == 8 || tile_h == 4 || tile_h == 2) && item_slots >= 2 && item_slots <= 16, "tile / slot geometry");
+    static constexpr int tile_h = RT_TILE_H, tile_px = 8 * tile_h, tile_shift = tile_h == 8 ? 6 : tile_h == 4 ? 5 : tile_h == 2 ? 4 : 3;
+    static constexpr int slot_acc = tile_px * 3;                               // accumulator cells per slot
+    static constexpr int wave_acc = item_slots * slot_acc;                     // accumulator cells per wave
+    static constexpr int nan_words = (slot_acc + 31) / 32;                     // per slot: one "a NaN sample was added" bit per cell
+    static constexpr int state_ints = 4 * item_slots + 16 + nan_words * item_slots; // per slot: i0, j0, chunk, valid; the current item; NaN bits
+    static constexpr int wave_stride = wave_acc * 8 + state_ints * 4;          // bytes per wave
+    static_assert((tile_h == 8 || tile_h == 4 || tile_h == 2 || tile_h == 1) && item_slots >= 2 && item_slots <= 16, "tile / slot geometry");
+    static_assert(wave_stride % 8 == 0, "accumulator cells are 8-byte aligned");
     static constexpr int wave_off = 0;
     static constexpr int stream_off = wave_off + waves * wave_stride;
     static constexpr int total_bytes = sizeof(R) == 4 ? 160 * 1024 - 512 : 160 * 1024 - 512 - 16 * 1024;

@@ -3,13 +3,14 @@ checked through properties that do not need a CPU run of 2 G samples:
 
 * the multi-GPU decomposition: the 8 per-rank stratum ranges of `split_range(961, 8, r)` sum to the whole frame, with
   exactly the same number of rays (the RNG is keyed by (pixel, stratum), so every path is the same path);
-* a rank's partial frame repeats run to run: same rays, sums equal to float rounding;
+* a rank's partial frame repeats run to run BIT FOR BIT (the float kernels accumulate in 64-bit fixed point: integer adds
+  commute, so neither the atomic work-item cursor nor the order in which a wave's paths finish can show in a sum);
 * agreement with the compiled reference: the 1080p frame box-averaged 40x40 -> 48x27 is the same integral as the
   reference's converged 48x27 frame of the same camera (tests/golden/conv3.npz, 422.5k spp): PSNR >= 40 dB in 8-bit
   display space.
 
-f32 tolerances: per-pixel sums of 961 samples accumulated in different orders (whole frame vs 8 partial frames) agree to
-2e-4 relative (float accumulation, one rounding per add), 1e-3 absolute."""
+The whole frame and the sum of its 8 per-rank frames are the same integer total; each is rounded to float once per
+frame it passes through, so they agree to 8 float roundings of the partial sums: 1 ulp of the total (1.2e-7 relative)."""
 import numpy as np
 import pytest
 
@@ -55,23 +56,23 @@ def test_rank_ranges_sum_to_the_whole_frame(headline, whole):
     assert rays == st["rays"], "same paths whatever the decomposition"
     ok = np.isfinite(acc)
     assert (~ok).sum() <= 64 and np.array_equal(ok, np.isfinite(total))
-    np.testing.assert_allclose(total[ok], acc[ok].astype(np.float64), rtol=2e-4, atol=1e-3)
+    # every rank's frame is its exact fixed-point sum rounded to float (<= 2^-25 relative each): the double sum of the 8
+    # is within 2^-25 of the exact total, whose own float rounding is another 2^-25
+    np.testing.assert_allclose(total[ok], acc[ok].astype(np.float64), rtol=2.0 ** -23, atol=0)
 
 
-def test_partial_frame_repeats_to_float_rounding(headline):
-    """Two runs trace the same paths (same ray count).  Which wave picks up which work item is decided by an atomic
-    cursor, and the order in which a wave's finished paths are added to a pixel follows that wave's schedule, so at
-    this size (every wave handles ~60 items) the float sums repeat to rounding (1e-5 relative), not to the bit; frames
-    small enough for one item per wave repeat exactly (test_gpu_parity)."""
+def test_partial_frame_repeats_bit_for_bit(headline):
+    """Two runs trace the same paths (same ray count); which wave picks up which work item is decided by an atomic cursor
+    and the order of a wave's adds follows its schedule -- and none of that shows: the sums are integers until the last
+    conversion.  The same holds across different cuts of the sample range into chunks."""
     scene, ds = headline
     s0, s1 = split_range(961, 8, 3)
     a, _, sa = ds.render(scene.camera, seed=7, s_begin=s0, s_end=s1, precision=abi.RT_PREC_F32, want_rgb8=False)
     b, _, sb = ds.render(scene.camera, seed=7, s_begin=s0, s_end=s1, precision=abi.RT_PREC_F32, want_rgb8=False)
     assert sa["rays"] == sb["rays"]
-    ok = np.isfinite(a)
-    assert np.array_equal(ok, np.isfinite(b))
-    np.testing.assert_allclose(a[ok], b[ok], rtol=1e-5, atol=1e-4)
-    print(f"values that differ between two runs: {int((a[ok] != b[ok]).sum())} of {int(ok.sum())}")
+    assert a.tobytes() == b.tobytes(), f"{int((a != b).sum())} of {a.size} values differ between two runs"
+    c, _, sc_ = ds.render(scene.camera, seed=7, s_begin=s0, s_end=s1, precision=abi.RT_PREC_F32, sample_chunks=5, want_rgb8=False)
+    assert sc_["rays"] == sa["rays"] and c.tobytes() == a.tobytes(), "the cut into sample chunks must not show either"
 
 
 def test_full_frame_downsampled_matches_converged_reference(headline, whole):

@@ -159,11 +159,13 @@ def test_sample_range_split_sums_to_whole_and_is_chunk_invariant(scenes):
     whole, _, _ = scenes[2].render(cam, seed=9, precision=abi.RT_PREC_F32, sample_chunks=1)
     parts = [scenes[2].render(cam, seed=9, s_begin=a, s_end=b, precision=abi.RT_PREC_F32)[0]
              for a, b in ((0, 5), (5, 17), (17, 36))]
-    np.testing.assert_allclose(sum(p.astype(np.float64) for p in parts), whole, rtol=2e-6, atol=1e-6)
+    ok = np.isfinite(whole)
+    np.testing.assert_allclose(sum(p.astype(np.float64) for p in parts)[ok], whole[ok], rtol=2.0 ** -23, atol=0)
+    # fixed-point accumulation: the cut into chunks cannot show, and frames repeat bit for bit
     chunked, _, _ = scenes[2].render(cam, seed=9, precision=abi.RT_PREC_F32, sample_chunks=7)
-    np.testing.assert_allclose(chunked, whole, rtol=2e-6, atol=1e-6)
+    assert chunked.tobytes() == whole.tobytes()
     again, _, _ = scenes[2].render(cam, seed=9, precision=abi.RT_PREC_F32, sample_chunks=7)
-    assert again.tobytes() == chunked.tobytes(), "repeats exactly while every wave holds one work item (small frames)"
+    assert again.tobytes() == chunked.tobytes()
     empty, _, st = scenes[2].render(cam, seed=9, s_begin=4, s_end=4)
     assert st["samples"] == 0 and not empty.any()
 
