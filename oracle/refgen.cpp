@@ -589,7 +589,54 @@ static void on_render(camera &cam, const hittable &world, const hittable &lights
     exit(2);
 }
 
-// usage: refgen <mode> <scene 1..4|5(bounce frame)> <W> <H> <spp> <depth> <use_bvh 0|1> <out> [seed|extra_rays] [frame]
+// Scene 6, "cornell smoke": not one of the reference's own scene functions -- a scene a user of its API can write (it is
+// the book's cornell_smoke pattern) -- built here with the REFERENCE's classes so that the reference's own
+// constant_medium::hit runs boundary->hit() on boundaries that are not spheres: rotated + translated box() lists, a
+// box() list in world space, a moving sphere.  raytracing_amd/host/scenes.cpp builds the same scene with the drop-in API.
+static void cornell_smoke(int image_width, double aspect_ratio, int samples_per_pixel, int max_depth, bool use_bvh) {
+    hittable_list world;
+    auto red = make_shared<lambertian>(color(.65, .05, .05));
+    auto white = make_shared<lambertian>(color(.73, .73, .73));
+    auto green = make_shared<lambertian>(color(.12, .45, .15));
+    auto light = make_shared<diffuse_light>(color(7, 7, 7));
+    world.add(make_shared<quad>(point3(555, 0, 0), vec3(0, 0, 555), vec3(0, 555, 0), green));
+    world.add(make_shared<quad>(point3(0, 0, 555), vec3(0, 0, -555), vec3(0, 555, 0), red));
+    world.add(make_shared<quad>(point3(0, 555, 0), vec3(555, 0, 0), vec3(0, 0, 555), white));
+    world.add(make_shared<quad>(point3(0, 0, 555), vec3(555, 0, 0), vec3(0, 0, -555), white));
+    world.add(make_shared<quad>(point3(555, 0, 555), vec3(-555, 0, 0), vec3(0, 555, 0), white));
+    world.add(make_shared<quad>(point3(113, 554, 127), vec3(330, 0, 0), vec3(0, 0, 305), light));
+    shared_ptr<hittable> box1 = box(point3(0, 0, 0), point3(165, 330, 165), white);
+    box1 = make_shared<rotate_y>(box1, 15);
+    box1 = make_shared<translate>(box1, vec3(265, 0, 295));
+    shared_ptr<hittable> box2 = box(point3(0, 0, 0), point3(165, 165, 165), white);
+    box2 = make_shared<rotate_y>(box2, -18);
+    box2 = make_shared<translate>(box2, vec3(130, 0, 65));
+    world.add(make_shared<constant_medium>(box1, 0.01, color(0, 0, 0)));
+    world.add(make_shared<constant_medium>(box2, 0.01, color(1, 1, 1)));
+    world.add(make_shared<constant_medium>(box(point3(30, 380, 300), point3(140, 470, 420), white), 0.02, color(.2, .4, .9)));
+    world.add(make_shared<constant_medium>(make_shared<sphere>(point3(400, 420, 200), point3(430, 420, 200), 50, white), 0.05,
+                                           color(.9, .6, .2)));
+    world.add(make_shared<sphere>(point3(190, 90, 190), 60, make_shared<dielectric>(1.5)));
+    if (use_bvh) world = hittable_list(make_shared<bvh_node>(world));
+    auto empty_material = shared_ptr<material>();
+    hittable_list lights;
+    lights.add(make_shared<quad>(point3(443, 554, 432), vec3(-330, 0, 0), vec3(0, 0, -305), empty_material));
+    camera renderer;
+    renderer.aspect_ratio = aspect_ratio;
+    renderer.image_width = image_width;
+    renderer.samples_per_pixel = samples_per_pixel;
+    renderer.max_depth = max_depth;
+    renderer.background = color(0, 0, 0);
+    renderer.use_bvh = use_bvh;
+    renderer.vfov = 40;
+    renderer.lookfrom = point3(278, 278, -800);
+    renderer.lookat = point3(278, 278, 0);
+    renderer.vup = vec3(0, 1, 0);
+    renderer.defocus_angle = 0;
+    on_render(renderer, world, lights);
+}
+
+// usage: refgen <mode> <scene 1..4|5(bounce frame)|6(cornell smoke)> <W> <H> <spp> <depth> <use_bvh 0|1> <out> [seed|extra_rays] [frame]
 #undef main
 int main(int argc, char **argv) {
     if (argc == 4 && std::string(argv[1]) == "teximg") { // refgen teximg <image file> <out>: the reference's rtw_image::load
@@ -636,6 +683,7 @@ int main(int argc, char **argv) {
     case 3: final_scene(W, aspect, spp, depth, false, 1, "x.ppm", use_bvh, false, 0); break;
     case 4: mesh_scene(W, aspect, spp, depth, false, 1, "x.ppm", use_bvh, false, 0); break;
     case 5: first_scene_moving(W, aspect, spp, depth, false, 1, "x.ppm", use_bvh, true, 2, 20, frame); break;
+    case 6: cornell_smoke(W, aspect, spp, depth, use_bvh); break;
     default: fprintf(stderr, "bad scene\n"); return 2;
     }
     return 0;

@@ -176,6 +176,7 @@ template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, Device
                     (size_t)s.n_units * sizeof(UnitT<R>) + tab_bytes <= (size_t)LaunchCfg<R>::lds_bytes) ? 1 : 0;
     s.n_lights = (int)f.lights.size();
     s.lights_is_list = f.lights_is_list;
+    s.has_gen_medium = f.has_gen_medium;
     ds.n_fused_boxes = f.n_fused_boxes;
     return RT_OK;
 }

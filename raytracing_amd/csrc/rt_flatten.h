@@ -4,6 +4,7 @@
 #define RT_FLATTEN_H
 
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include <utility>
 #include <vector>
@@ -25,6 +26,7 @@ template <class R> struct Flat {
     int lights_is_list = 0;
     int n_fused_boxes = 0;
     int n_baked_instances = 0; // translate / rotate_y subtrees of plain spheres emitted in world space (f32 stream)
+    int has_gen_medium = 0;    // the stream holds MEDIUM_GEN records (kernels with the sub-stream walk are launched)
 };
 
 // conversions double -> R; boxes are rounded outward so that an f32 box always contains the f64 one
@@ -57,6 +59,22 @@ template <class R> class Flattener {
         int rc = validate();
         if (rc) return rc;
         convert_tables();
+        // FLAT float BOX records are widened to what float can resolve at the scale of the scene.  The reference pads flat
+        // boxes to 1e-4 (aabb.h:74-81: a wall quad's box); in float, with coordinates of several hundred, that is thinner
+        // than one ulp of the slab distances (b * (1/d) - o * (1/d), each part ~1e2: 8e-6 apart at best): the near and
+        // far distances of such a box round to the same number and the box -- with the wall in it -- is missed.  A side
+        // thinner than 64 ulp of twice the largest world coordinate gets 32 ulp on either end (box_hit also accepts
+        // near == far).  Only flat sides: widening EVERY box, even by 4 ulp, lets each ray that leaves a surface re-enter
+        // the box of the object it just left (its exit distance then exceeds t_min = 0.001): +1 % frame time measured.
+        if constexpr (sizeof(R) == 4) {
+            double m = 0;
+            for (int a = 0; a < 6; a++) {
+                const double v = std::fabs(d_.nodes[d_.world_root].bbox[a]);
+                if (std::isfinite(v)) m = std::fmax(m, v);
+            }
+            box_pad_ = 32.0 * 5.9604644775390625e-08 * 2.0 * m;
+            if (const char *e = std::getenv("RT_AMD_BOX_PAD_ULPS")) box_pad_ = std::atof(e) * 5.9604644775390625e-08 * 2.0 * m; // development knob
+        }
         f_.xforms.push_back(XformT<R>{}); // context 0 = world space
         rc = emit(d_.world_root, 0, 0);
         if (rc) return rc;
@@ -64,6 +82,17 @@ template <class R> class Flattener {
         // "traversal finished", so a traversal step never needs a bounds check
         const int end = push_units(2, -1);
         f_.stream[end + 1].w[3] = I(make_hdr(K_READY, 0));
+        // boundaries of constant_mediums that are not a static sphere: one sub-stream each, behind the main stream, in the
+        // transform context of its medium and with a sentinel of its own (constant_medium.h:24-28 runs boundary->hit twice)
+        for (size_t k = 0; k < pending_.size(); k++) {
+            const Pending pd = pending_[k];
+            f_.stream[pd.record].w[0] = I((int)f_.stream.size());
+            rc = emit(pd.boundary, pd.ctx, 0);
+            if (rc) return rc;
+            const int e2 = push_units(2, -1);
+            f_.stream[e2 + 1].w[3] = I(make_hdr(K_READY, 0));
+        }
+        f_.has_gen_medium = pending_.empty() ? 0 : 1;
         return emit_lights();
     }
 
@@ -72,6 +101,11 @@ template <class R> class Flattener {
     Flat<R> &f_;
     std::string &err_;
     bool fuse_;
+    struct Pending { // a MEDIUM_GEN record waiting for its boundary sub-stream
+        int record, boundary, ctx;
+    };
+    std::vector<Pending> pending_;
+    double box_pad_ = 0; // float streams: see run()
     static constexpr size_t kMaxUnits = size_t(1) << 26;
 
     int fail(int code, const std::string &msg) {
@@ -178,6 +212,22 @@ template <class R> class Flattener {
                 return fail(RT_ERR_INVALID, "image out of range");
         }
         return RT_OK;
+    }
+
+    bool contains_medium(int id, int rdepth) const {
+        if (rdepth > 256) return false;
+        const rt_node &n = d_.nodes[id];
+        switch (n.kind) {
+        case RT_NODE_MEDIUM: return true;
+        case RT_NODE_BVH: return contains_medium(n.a, rdepth + 1) || contains_medium(n.b, rdepth + 1);
+        case RT_NODE_LIST:
+            for (int k = 0; k < n.b; k++)
+                if (contains_medium(d_.child_index[n.a + k], rdepth + 1)) return true;
+            return false;
+        case RT_NODE_TRANSLATE:
+        case RT_NODE_ROTATE_Y: return contains_medium(n.a, rdepth + 1);
+        default: return false;
+        }
     }
 
     bool tex_needs_uv(int tex, int guard = 0) const {
@@ -410,8 +460,9 @@ template <class R> class Flattener {
             }
             R rl[3], rh[3];
             for (int a = 0; a < 3; a++) {
-                cvt_lo(lo[a], rl[a]);
-                cvt_hi(hi[a], rh[a]);
+                const double pad = (hi[a] - lo[a]) < 2 * box_pad_ ? box_pad_ : 0.0;
+                cvt_lo(lo[a] - pad, rl[a]);
+                cvt_hi(hi[a] + pad, rh[a]);
             }
             f_.stream[self] = UnitT<R>{{rl[0], rh[0], rl[1], rh[1]}};
             f_.stream[self + 1] = UnitT<R>{{rl[2], rh[2], I((int)f_.stream.size()), I(make_hdr(K_BOX, 0))}};
@@ -476,8 +527,9 @@ template <class R> class Flattener {
             const int self = push_units(2, id);
             R lo[3], hi[3];
             for (int a = 0; a < 3; a++) {
-                cvt_lo(n.bbox[2 * a], lo[a]);
-                cvt_hi(n.bbox[2 * a + 1], hi[a]);
+                const double pad = (n.bbox[2 * a + 1] - n.bbox[2 * a]) < 2 * box_pad_ ? box_pad_ : 0.0;
+                cvt_lo(n.bbox[2 * a] - pad, lo[a]);
+                cvt_hi(n.bbox[2 * a + 1] + pad, hi[a]);
             }
             f_.stream[self] = UnitT<R>{{lo[0], hi[0], lo[1], hi[1]}};
             f_.stream[self + 1] = UnitT<R>{{lo[2], hi[2], I(0), I(make_hdr(K_BOX, 0))}};
@@ -545,11 +597,17 @@ template <class R> class Flattener {
         }
         case RT_NODE_MEDIUM: {
             const rt_node &b = d_.nodes[n.a];
-            if (b.kind != RT_NODE_SPHERE)
-                return fail(RT_ERR_UNSUPPORTED, "constant_medium boundary must be a sphere on the device path");
+            const bool static_sphere = b.kind == RT_NODE_SPHERE && d_.spheres[b.a].dcenter[0] == 0 && d_.spheres[b.a].dcenter[1] == 0 &&
+                                       d_.spheres[b.a].dcenter[2] == 0;
+            if (!static_sphere) { // any other hittable: its records become a sub-stream that the MEDIUM_GEN step walks twice
+                if (contains_medium(n.a, 0)) return fail(RT_ERR_UNSUPPORTED, "constant_medium inside the boundary of a constant_medium");
+                const int off = push_units(2, id);
+                f_.stream[off] = UnitT<R>{{I(0), R(0), R(0), R(0)}};
+                f_.stream[off + 1] = UnitT<R>{{F(n.p[0]), I(n.b), I(id), I(make_hdr(K_MEDIUM_GEN, 0))}};
+                pending_.push_back(Pending{off, n.a, ctx});
+                return RT_OK;
+            }
             const rt_sphere &s = d_.spheres[b.a];
-            if (s.dcenter[0] != 0 || s.dcenter[1] != 0 || s.dcenter[2] != 0)
-                return fail(RT_ERR_UNSUPPORTED, "constant_medium boundary must be a static sphere on the device path");
             const int off = push_units(2, id);
             f_.stream[off] = UnitT<R>{{F(s.center[0]), F(s.center[1]), F(s.center[2]), F(s.radius)}};
             f_.stream[off + 1] = UnitT<R>{{F(n.p[0]), I(n.b), I(id), I(make_hdr(K_MEDIUM, 0))}};

@@ -286,7 +286,7 @@ RT_DEV bool box_hit(const UnitT<R> &u0, const UnitT<R> &u1, V3<R> o, V3<R> inv, 
         float far_z;
         asm("v_min_f32 %0, %1, %2" : "=v"(far_z) : "v"(m_max(tz.x, tz.y)), "v"(tmax));
         R tf = m_min(m_min(m_max(tx.x, tx.y), m_max(ty.x, ty.y)), far_z);
-        return tf > tn;
+        return tf >= tn; // (a box thinner than the float resolution of its distances still counts: rt_flatten.h pads, too)
     } else {
         {
             R t0 = (bx0 - o.x) * inv.x, t1 = (bx1 - o.x) * inv.x;
@@ -410,7 +410,23 @@ RT_DEV bool tri_t(V3<R> v0, V3<R> edge1, V3<R> edge2, int cull, V3<R> ro, V3<R> 
     return true;
 }
 
-// constant_medium.h:21 (boundary is a static sphere); the uniform is drawn only where the reference draws it (line 41)
+// constant_medium.h:30-44: the boundary is entered at t1 and left at t2 (both hits found); clip to the ray's interval, draw
+// the free path.  The uniform is drawn only where the reference draws it (line 41).
+template <class R, class XiFn>
+RT_DEV bool medium_span(R t1, R t2, R neg_inv_density, int node_id, V3<R> rd, R tmin, R tmax, XiFn xi_fn, R &t_out) {
+    if (t1 < tmin) t1 = tmin;
+    if (t2 > tmax) t2 = tmax;
+    if (t1 >= t2) return false;
+    if (t1 < R(0)) t1 = R(0);
+    R ray_length = len(rd);
+    R distance_inside_boundary = (t2 - t1) * ray_length;
+    R hit_distance = neg_inv_density * m_log(xi_fn(node_id));
+    if (hit_distance > distance_inside_boundary) return false;
+    t_out = t1 + m_div(hit_distance, ray_length);
+    return true;
+}
+
+// constant_medium.h:21 (boundary is a static sphere)
 template <class R, class XiFn>
 RT_DEV bool medium_t(V3<R> cc, R radius, R neg_inv_density, int node_id, V3<R> ro, V3<R> rd, R tmin, R tmax, XiFn xi_fn,
                      R &t_out) {
@@ -435,16 +451,7 @@ RT_DEV bool medium_t(V3<R> cc, R radius, R neg_inv_density, int node_id, V3<R> r
         if (!sphere_t(cc, radius, ro, rd, -Const<R>::inf, Const<R>::inf, t1)) return false;
         if (!sphere_t(cc, radius, ro, rd, t1 + R(0.0001), Const<R>::inf, t2)) return false;
     }
-    if (t1 < tmin) t1 = tmin;
-    if (t2 > tmax) t2 = tmax;
-    if (t1 >= t2) return false;
-    if (t1 < R(0)) t1 = R(0);
-    R ray_length = len(rd);
-    R distance_inside_boundary = (t2 - t1) * ray_length;
-    R hit_distance = neg_inv_density * m_log(xi_fn(node_id));
-    if (hit_distance > distance_inside_boundary) return false;
-    t_out = t1 + m_div(hit_distance, ray_length);
-    return true;
+    return medium_span(t1, t2, neg_inv_density, node_id, rd, tmin, tmax, xi_fn, t_out);
 }
 
 template <class R> RT_DEV void xf_apply(int kind, R p0, R p1, R p2, V3<R> &o, V3<R> &d) {
@@ -529,8 +536,8 @@ RT_DEV void trav_box_step(const Mem<R, ALL_LDS> &mem, Trav<R> &tv, R tmin) {
     trav_goto(mem, tv, hit ? tv.i + 2 : ldi(tv.u1.w[2]));
 }
 
-// One non-BOX record.
-template <class R, bool ALL_LDS, class SC, class MediumXi>
+// One non-BOX record.  GM: the stream may hold MEDIUM_GEN records (a constant_medium whose boundary is a sub-stream).
+template <bool GM, class R, bool ALL_LDS, class SC, class MediumXi>
 RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SC &sc, Trav<R> &tv, const RayT<R> &world, R tmin,
                            MediumXi medium_xi) {
     const int kind = tv.hdr & 15;
@@ -573,6 +580,31 @@ RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SC &sc, Trav<R> &tv
         if (medium_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], tv.u1.w[0], ldi(tv.u1.w[2]), tv.o, tv.d, tmin,
                      tv.best_t, medium_xi, t)) {
             tv.best_t = t; tv.best_off = i; tv.best_ctx = tv.ctx;
+        }
+    } else if (GM && kind == K_MEDIUM_GEN) {
+        if constexpr (GM) {
+            // constant_medium.h:24-28: boundary->hit(r, universe, rec1), then boundary->hit(r, (rec1.t + 0.0001, inf), rec2) --
+            // two closest-hit walks of the boundary's sub-stream (its own records, transforms and sentinel), starting in
+            // this medium's frame.  Only the distances are used.  (A medium inside a boundary is refused at upload, so
+            // the walk never nests.)
+            const int sub_off = ldi(tv.u0.w[0]);
+            auto boundary_hit = [&](R lo, R &t_hit) {
+                Trav<R> s;
+                s.o = tv.o; s.d = tv.d; s.inv = tv.inv; s.noi = tv.noi;
+                s.best_t = Const<R>::inf; s.best_off = -1; s.best_ctx = tv.ctx; s.ctx = tv.ctx;
+                trav_goto(mem, s, sub_off);
+                while ((s.hdr & 15) != K_READY) {
+                    if ((s.hdr & 15) == K_BOX) trav_box_step(mem, s, lo);
+                    else trav_leaf_step<false>(mem, sc, s, world, lo, medium_xi);
+                }
+                t_hit = s.best_t;
+                return s.best_off >= 0;
+            };
+            R t1, t2, t;
+            if (boundary_hit(-Const<R>::inf, t1) && boundary_hit(t1 + R(0.0001), t2) &&
+                medium_span(t1, t2, tv.u1.w[0], ldi(tv.u1.w[2]), tv.d, tmin, tv.best_t, medium_xi, t)) {
+                tv.best_t = t; tv.best_off = i; tv.best_ctx = tv.ctx;
+            }
         }
     } else if (kind == K_XF_ENTER) {
         xf_apply(ldi(tv.u1.w[0]), tv.u0.w[0], tv.u0.w[1], tv.u0.w[2], tv.o, tv.d);
@@ -1137,7 +1169,7 @@ enum : int { A_BOX = 0, A_SPHERE = 1, A_AABOX = 2, A_MEDIUM = 3, A_OTHER = 4, A_
 enum : int { WS_SLOT_I0 = 0, WS_SLOT_J0 = 1, WS_SLOT_CHUNK = 2, WS_SLOT_VALID = 3, WS_CUR_SLOT = 4 * RT_ITEM_SLOTS, WS_CUR_S0 = 4 * RT_ITEM_SLOTS + 1,
               WS_N_UNITS = 4 * RT_ITEM_SLOTS + 2, WS_NAN = 4 * RT_ITEM_SLOTS + 16 /* nan_words ints per slot */ };
 
-template <class R, bool ALL_LDS, bool TAB_LDS, int BLOCK>
+template <class R, bool ALL_LDS, bool TAB_LDS, bool GEN_MEDIUM, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT<R> cam_arg, RenderArgs a_arg, void *__restrict__ out_,
                                                        unsigned long long *__restrict__ counters) {
     using Cell = typename CellOf<R>::T;
@@ -1311,7 +1343,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                 for (int rep = 0; rep < RT_OTHER_REPEAT; rep++) {
                     if (at) {
                         auto mxi = [&](int node_id) { return medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce); };
-                        trav_leaf_step(mem, sc, tv, ray, tmin, mxi);
+                        trav_leaf_step<GEN_MEDIUM>(mem, sc, tv, ray, tmin, mxi);
                     }
                     int h = tv.hdr;
                     at = at && (h & 15) >= K_QUAD && (h & 15) < K_IDLE;
@@ -1516,7 +1548,7 @@ struct TraceArgs {
 };
 
 // rt_trace_batch: closest hit of each ray over [0.001, inf) (camera.h:300).
-template <class R, bool ALL_LDS, bool TAB_LDS, int BLOCK>
+template <class R, bool ALL_LDS, bool TAB_LDS, bool GEN_MEDIUM, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) trace_kernel(SceneT<R> sc_arg, const rt_ray *__restrict__ rays, const double *__restrict__ xi,
                                                       size_t n, rt_hit *__restrict__ out, TraceArgs a) {
     const SceneV<R, TAB_LDS> sc = stage_scene<R, TAB_LDS>(sc_arg);
@@ -1537,7 +1569,7 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(SceneT<R> sc_arg, const rt
         trav_begin(mem, tv, r);
         while ((tv.hdr & 15) != K_READY) {
             if ((tv.hdr & 15) == K_BOX) trav_box_step(mem, tv, R(0.001));
-            else trav_leaf_step(mem, sc, tv, r, R(0.001), mxi);
+            else trav_leaf_step<GEN_MEDIUM>(mem, sc, tv, r, R(0.001), mxi);
         }
         rt_hit o;
         o.prim = -1;

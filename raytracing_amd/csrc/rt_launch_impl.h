@@ -42,9 +42,18 @@ hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const Rende
         hipLaunchKernelGGL(k, grid, block, lds + C::stream_off, stream, sc, cam, a, out, counters);
         return hipSuccess;
     };
-    if (sc.lds_units == sc.n_units && sc.tab_in_lds) e = go(render_kernel<R, true, true, C::block>);
-    else if (sc.lds_units == sc.n_units) e = go(render_kernel<R, true, false, C::block>);
-    else e = go(render_kernel<R, false, false, C::block>);
+    // (the kernels that can walk a constant_medium's boundary sub-stream are separate instantiations: that walk keeps a
+    // second traversal state alive, which the common scenes' kernels should not pay for in registers)
+    const bool all = sc.lds_units == sc.n_units, tab = all && sc.tab_in_lds;
+    if (sc.has_gen_medium) {
+        if (tab) e = go(render_kernel<R, true, true, true, C::block>);
+        else if (all) e = go(render_kernel<R, true, false, true, C::block>);
+        else e = go(render_kernel<R, false, false, true, C::block>);
+    } else {
+        if (tab) e = go(render_kernel<R, true, true, false, C::block>);
+        else if (all) e = go(render_kernel<R, true, false, false, C::block>);
+        else e = go(render_kernel<R, false, false, false, C::block>);
+    }
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }
@@ -69,9 +78,16 @@ hipError_t launch_trace(const SceneT<R> &sc, const rt_ray *d_rays, const double 
         hipLaunchKernelGGL(k, grid, block, lds + C::stream_off, stream, sc, d_rays, d_xi, n, d_out, a);
         return hipSuccess;
     };
-    if (sc.lds_units == sc.n_units && sc.tab_in_lds) e = go(trace_kernel<R, true, true, C::block>);
-    else if (sc.lds_units == sc.n_units) e = go(trace_kernel<R, true, false, C::block>);
-    else e = go(trace_kernel<R, false, false, C::block>);
+    const bool all = sc.lds_units == sc.n_units, tab = all && sc.tab_in_lds;
+    if (sc.has_gen_medium) {
+        if (tab) e = go(trace_kernel<R, true, true, true, C::block>);
+        else if (all) e = go(trace_kernel<R, true, false, true, C::block>);
+        else e = go(trace_kernel<R, false, false, true, C::block>);
+    } else {
+        if (tab) e = go(trace_kernel<R, true, true, false, C::block>);
+        else if (all) e = go(trace_kernel<R, true, false, false, C::block>);
+        else e = go(trace_kernel<R, false, false, false, C::block>);
+    }
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }

@@ -18,7 +18,11 @@
 //   AABOX   (box())      2   x.min, x.max, y.min, y.max   z.min, z.max, mat, hdr(payload = 6 face-orientation bits)
 //   QUAD                 5   n.xyz, D                  Q.xyz, hdr                         u.xyz, mat | v.xyz, area | w.xyz, -
 //   TRI                  3   v0.xyz, e1.x              e1.y, e1.z, e2.x, hdr              e2.y, e2.z, mat, cull
-//   MEDIUM               2   c.xyz, radius (boundary)  -1/density, mat, node_id, hdr
+//   MEDIUM               2   c.xyz, radius (boundary)  -1/density, mat, node_id, hdr      (boundary = static sphere, inline)
+//   MEDIUM_GEN           2   sub-stream offset, -, -, -  -1/density, mat, node_id, hdr     (any other boundary: box(), instances,
+//                                                                                         lists, a bvh ...; its records form a
+//                                                                                         sub-stream with a sentinel of its own,
+//                                                                                         placed behind the main stream's)
 //   XF_ENTER             2   p0, p1, p2, -             xf kind, ctx id, -, hdr            (translate: offset; rotate_y: sin, cos)
 //   XF_EXIT              2   p0, p1, p2, -             xf kind, parent ctx id, -, hdr     (same parameters as its XF_ENTER)
 //   (end)                2   -                         -, -, -, hdr = K_READY             sentinel behind the last record
@@ -49,6 +53,7 @@ enum : int {
     K_XF_ENTER = 6,
     K_XF_EXIT = 7,
     K_MSPHERE = 8, // moving sphere (3 units)
+    K_MEDIUM_GEN = 9, // constant_medium whose boundary is not a static sphere: the boundary is a sub-stream of its own
     K_IDLE = 14,
     K_READY = 15,
 };
@@ -187,6 +192,7 @@ template <class R> struct SceneT { // device pointers; passed to kernels by valu
     int32_t lds_units; // leading units of `stream` that the kernels stage into LDS
     int32_t n_lights;
     int32_t lights_is_list; // lights_root is a hittable_list (hittable_list.h:52 draws the pick) vs a bare shape
+    int32_t has_gen_medium; // MEDIUM_GEN records present: launch the kernels that can walk a boundary sub-stream
 };
 
 // LDS map of a workgroup (all offsets are compile-time constants, so no register holds them):

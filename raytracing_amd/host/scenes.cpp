@@ -117,6 +117,38 @@ void cornell_box(BuiltScene &s, bool use_bvh) { // cpuRenderer.cpp:227
     cornell_camera(s.cam, point3(278, 278, -800));
 }
 
+// Scene 6, "cornell smoke": not one of the reference's scene functions, a scene its API permits (the book's cornell_smoke
+// pattern): constant_mediums bounded by rotated + translated box() lists, by a box() list in world space and by a moving
+// sphere.  oracle/refgen.cpp builds the same scene with the reference's own classes (fixtures tests/golden/*6.npz).
+void cornell_smoke(BuiltScene &s, bool use_bvh) {
+    auto red = make_shared<lambertian>(color(.65, .05, .05));
+    auto white = make_shared<lambertian>(color(.73, .73, .73));
+    auto green = make_shared<lambertian>(color(.12, .45, .15));
+    auto light = make_shared<diffuse_light>(color(7, 7, 7));
+    s.world.add(make_shared<quad>(point3(555, 0, 0), vec3(0, 0, 555), vec3(0, 555, 0), green));
+    s.world.add(make_shared<quad>(point3(0, 0, 555), vec3(0, 0, -555), vec3(0, 555, 0), red));
+    s.world.add(make_shared<quad>(point3(0, 555, 0), vec3(555, 0, 0), vec3(0, 0, 555), white));
+    s.world.add(make_shared<quad>(point3(0, 0, 555), vec3(555, 0, 0), vec3(0, 0, -555), white));
+    s.world.add(make_shared<quad>(point3(555, 0, 555), vec3(-555, 0, 0), vec3(0, 555, 0), white));
+    s.world.add(make_shared<quad>(point3(113, 554, 127), vec3(330, 0, 0), vec3(0, 0, 305), light));
+    shared_ptr<hittable> box1 = box(point3(0, 0, 0), point3(165, 330, 165), white);
+    box1 = make_shared<rotate_y>(box1, 15);
+    box1 = make_shared<translate>(box1, vec3(265, 0, 295));
+    shared_ptr<hittable> box2 = box(point3(0, 0, 0), point3(165, 165, 165), white);
+    box2 = make_shared<rotate_y>(box2, -18);
+    box2 = make_shared<translate>(box2, vec3(130, 0, 65));
+    s.world.add(make_shared<constant_medium>(box1, 0.01, color(0, 0, 0)));
+    s.world.add(make_shared<constant_medium>(box2, 0.01, color(1, 1, 1)));
+    s.world.add(make_shared<constant_medium>(box(point3(30, 380, 300), point3(140, 470, 420), white), 0.02, color(.2, .4, .9)));
+    s.world.add(make_shared<constant_medium>(make_shared<sphere>(point3(400, 420, 200), point3(430, 420, 200), 50, white), 0.05,
+                                             color(.9, .6, .2)));
+    s.world.add(make_shared<sphere>(point3(190, 90, 190), 60, make_shared<dielectric>(1.5)));
+    wrap_bvh(s.world, use_bvh);
+    auto none = shared_ptr<material>();
+    s.lights.add(make_shared<quad>(point3(443, 554, 432), vec3(-330, 0, 0), vec3(0, 0, -305), none));
+    cornell_camera(s.cam, point3(278, 278, -800));
+}
+
 void mesh_scene(BuiltScene &s, bool use_bvh, const std::string &asset_dir) { // cpuRenderer.cpp:166
     cornell_walls(s.world);
     auto mirror = make_shared<metal>(color(0.8, 0.85, 0.88), 0.0);
@@ -175,6 +207,7 @@ bool build_scene(int scene, bool use_bvh, int frame, const std::string &asset_di
     case 3: final_scene(out, use_bvh); return true;
     case 4: mesh_scene(out, use_bvh, asset_dir); return true;
     case 5: bounce_frame(out, use_bvh, frame); return true;
+    case 6: cornell_smoke(out, use_bvh); return true;
     }
     return false;
 }

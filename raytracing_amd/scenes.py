@@ -3,7 +3,8 @@ from __future__ import annotations
 
 from . import abi, host
 
-SCENE_IDS = {"first_scene": 1, "cornell_box": 2, "final_scene": 3, "mesh_scene": 4, "first_scene_moving": 5}
+SCENE_IDS = {"first_scene": 1, "cornell_box": 2, "final_scene": 3, "mesh_scene": 4, "first_scene_moving": 5,
+             "cornell_smoke": 6}  # 6: not a reference scene function; a scene its API permits (general medium boundaries)
 
 
 def build(name: str, image_width: int, image_height: int, samples_per_pixel: int, max_depth: int, use_bvh: bool = True,

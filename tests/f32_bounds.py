@@ -86,11 +86,15 @@ def _sphere_roots(c, r, o, d):
 def margin(sc: abi.Scene, nid: int, chain, ray, tmax: float, xi: float):
     """(hit?, t, margin): margin > 0 = the smallest slack (world units) of the accepted hit's tests, < 0 = by how much
     the most violated test of a miss fails.  tmax = the closest other hit (the interval the reference tests against)."""
+    o, d = to_object_space(chain, ray["orig"], ray["dir"])
+    return _prim_margin(sc, nid, o, d, float(ray["time"]), 0.001, tmax, xi)
+
+
+def _prim_margin(sc: abi.Scene, nid: int, o, d, time: float, tmin: float, tmax: float, xi: float = 0.5):
     n = sc.nodes[nid]
     kind = int(n["kind"])
-    o, d = to_object_space(chain, ray["orig"], ray["dir"])
     dl = math.sqrt(d @ d)
-    tmin = 0.001
+    ray = {"time": time}
     if kind == abi.RT_NODE_SPHERE:
         s = sc.spheres[int(n["a"])]
         c = np.array(s["center"]) + float(ray["time"]) * np.array(s["dcenter"])
@@ -132,13 +136,22 @@ def margin(sc: abi.Scene, nid: int, chain, ray, tmax: float, xi: float):
         l1, l2 = math.sqrt(e1 @ e1), math.sqrt(e2 @ e2)
         slack = min(u * l1, v * l2, (1 - u - v) * min(l1, l2), (t - tmin) * dl, (tmax - t) * dl)
         return slack >= 0, t if slack >= 0 else math.inf, slack
-    if kind == abi.RT_NODE_MEDIUM:  # constant_medium.h:21 with a sphere boundary
+    if kind == abi.RT_NODE_MEDIUM:  # constant_medium.h:21
         b = sc.nodes[int(n["a"])]
-        s = sc.spheres[int(b["a"])]
-        c, r = np.array(s["center"]), float(s["radius"])
-        t0, t1, m_disc = _sphere_roots(c, r, o, d)
-        if t0 is None:
-            return False, math.inf, m_disc
+        if int(b["kind"]) == abi.RT_NODE_SPHERE and not np.any(sc.spheres[int(b["a"])]["dcenter"]):
+            s = sc.spheres[int(b["a"])]
+            c, r = np.array(s["center"]), float(s["radius"])
+            t0, t1, m_disc = _sphere_roots(c, r, o, d)
+            if t0 is None:
+                return False, math.inf, m_disc
+        else:  # any other boundary: boundary->hit over the whole line, then behind the first hit (constant_medium.h:24-28)
+            t0, s0 = _closest(sc, int(n["a"]), o, d, float(ray["time"]), -math.inf)
+            if t0 is None:
+                return False, math.inf, s0
+            t1, s1 = _closest(sc, int(n["a"]), o, d, float(ray["time"]), t0 + 0.0001)
+            if t1 is None:
+                return False, math.inf, s1
+            m_disc = min(s0, s1)
         a0, a1 = max(t0, tmin), min(t1, tmax)
         if a0 >= a1:
             return False, math.inf, -(a0 - a1) * dl
@@ -149,6 +162,28 @@ def margin(sc: abi.Scene, nid: int, chain, ray, tmax: float, xi: float):
             return False, math.inf, -(hd - inside)
         return True, a0 + hd / dl, min(m_disc, inside - hd)
     return False, math.inf, -math.inf
+
+
+def _closest(sc: abi.Scene, nid: int, o, d, time: float, lo: float):
+    """closest hit of the sub-graph `nid` (a medium's boundary) with t in (lo, inf): (t, slack of the winner's tests) or
+    (None, minus the smallest miss).  o, d are in the sub-graph's frame."""
+    n = sc.nodes[nid]
+    kind = int(n["kind"])
+    if kind in (abi.RT_NODE_BVH, abi.RT_NODE_LIST):
+        kids = [int(n["a"]), int(n["b"])] if kind == abi.RT_NODE_BVH else [int(sc.arrays["child_index"][int(n["a"]) + j]) for j in range(int(n["b"]))]
+        best, slack, miss = None, None, -math.inf
+        for k in dict.fromkeys(kids):
+            t, s = _closest(sc, k, o, d, time, lo)
+            if t is None:
+                miss = max(miss, s)
+            elif best is None or t < best:
+                best, slack = t, s
+        return (best, slack) if best is not None else (None, miss)
+    if kind in (abi.RT_NODE_TRANSLATE, abi.RT_NODE_ROTATE_Y):
+        o2, d2 = to_object_space(((kind, tuple(float(x) for x in n["p"])),), o, d)
+        return _closest(sc, int(n["a"]), o2, d2, time, lo)
+    ok, t, m = _prim_margin(sc, nid, o, d, time, lo, math.inf)
+    return (t, m) if ok else (None, m)
 
 
 # ---- per-ray classification ------------------------------------------------------------------------------------------------
@@ -165,8 +200,8 @@ def _extent(sc, nid):
         kind = int(n["kind"])
     if kind == abi.RT_NODE_SPHERE:
         s = sc.spheres[int(n["a"])]
-        return float(np.abs(s["center"]).max()) + abs(float(s["radius"]))
-    return 0.0
+        return float(np.abs(s["center"]).max()) + float(np.abs(s["dcenter"]).max()) + abs(float(s["radius"]))
+    return float(np.abs(n["bbox"]).max()) if kind != abi.RT_NODE_QUAD and kind != abi.RT_NODE_TRIANGLE else 0.0
 
 
 def _cos_theta(ray, hit):
@@ -197,8 +232,7 @@ def classify(sc: abi.Scene, rays, ref, got, xi=None):
                 radius = abs(float(s["radius"]))
                 extra = float(np.abs(s["center"]).max()) + radius
             if kind == abi.RT_NODE_MEDIUM:
-                s = sc.spheres[int(nodes[int(nodes[r]["a"])]["a"])]
-                extra = float(np.abs(s["center"]).max()) + abs(float(s["radius"]))
+                extra = _extent(sc, r)
                 dens = abs(float(nodes[r]["p"][0]))
             M = _scale(ray, h, extra)
             cos = _cos_theta(ray, h) if kind != abi.RT_NODE_MEDIUM else 1.0

@@ -291,14 +291,25 @@ def make_boxtrace():
     print(f"boxtrace3: {len(rays)} rays, {(hits['prim'] >= 0).sum()} hits")
 
 
+def make_extras():
+    refgen("dump", 5, 64, 36, 9, 10, 1, f"{OUT}/scene5_f7.rtscene", 0, 7)
+    abi.Scene.load(f"{OUT}/scene5_f7.rtscene").save_npz(f"{GOLD}/scene5_f7.npz")
+    refgen("dump", 2, 64, 36, 9, 10, 0, f"{OUT}/scene2_nobvh.rtscene")
+    abi.Scene.load(f"{OUT}/scene2_nobvh.rtscene").save_npz(f"{GOLD}/scene2_nobvh.npz")
+    refgen("trace", 2, 64, 36, 9, 10, 0, f"{OUT}/trace2_nobvh.bin", 500)
+    rays, xi, hits = read_trace(f"{OUT}/trace2_nobvh.bin")
+    np.savez_compressed(f"{GOLD}/trace2_nobvh.npz", rays=rays.view("u1"), xi=xi, hits=hits.view("u1"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--converged", action="store_true", help="also (re)run the long converged renders")
-    ap.add_argument("--scenes", default="1,2,3,4")
+    ap.add_argument("--scenes", default="1,2,3,4,6")
     ap.add_argument("--anim-only", action="store_true", help="only (re)generate the animation fixtures")
     ap.add_argument("--jpeg-only", action="store_true", help="only (re)generate the JPEG decoding fixtures")
     ap.add_argument("--png-only", action="store_true", help="only (re)generate the PNG decoding fixtures")
     ap.add_argument("--boxtrace-only", action="store_true", help="only (re)generate the box corner / edge ray batch")
+    ap.add_argument("--smoke-only", action="store_true", help="only (re)generate scene 6 (cornell smoke: general medium boundaries)")
     a = ap.parse_args()
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
     os.makedirs(OUT, exist_ok=True)
@@ -311,18 +322,16 @@ def main():
     if a.boxtrace_only:
         make_boxtrace()
         return
-    make_anim()
-    if a.anim_only:
-        return
-    make_boxtrace()
+    if a.smoke_only:
+        a.scenes = "6"
+    if not a.smoke_only:
+        make_anim()
+        if a.anim_only:
+            return
+        make_boxtrace()
     # extra graph shapes: one frame of the bounce animation (cpuRenderer.cpp:19) and a scene without BVH
-    refgen("dump", 5, 64, 36, 9, 10, 1, f"{OUT}/scene5_f7.rtscene", 0, 7)
-    abi.Scene.load(f"{OUT}/scene5_f7.rtscene").save_npz(f"{GOLD}/scene5_f7.npz")
-    refgen("dump", 2, 64, 36, 9, 10, 0, f"{OUT}/scene2_nobvh.rtscene")
-    abi.Scene.load(f"{OUT}/scene2_nobvh.rtscene").save_npz(f"{GOLD}/scene2_nobvh.npz")
-    refgen("trace", 2, 64, 36, 9, 10, 0, f"{OUT}/trace2_nobvh.bin", 500)
-    rays, xi, hits = read_trace(f"{OUT}/trace2_nobvh.bin")
-    np.savez_compressed(f"{GOLD}/trace2_nobvh.npz", rays=rays.view("u1"), xi=xi, hits=hits.view("u1"))
+    if not a.smoke_only:
+        make_extras()
     for s in (int(x) for x in a.scenes.split(",")):
         refgen("dump", s, 64, 36, 9, 10, 1, f"{OUT}/scene{s}.rtscene")
         sc = abi.Scene.load(f"{OUT}/scene{s}.rtscene")

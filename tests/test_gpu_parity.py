@@ -16,13 +16,13 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def scenes(gpu_ctx):
-    out = {n: gpu_ctx.upload(fx.scene(n)) for n in (1, 2, 3, 4)}
+    out = {n: gpu_ctx.upload(fx.scene(n)) for n in (1, 2, 3, 4, 6)}
     yield out
     for ds in out.values():
         ds.close()
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 4])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 6])
 def test_trace_batch_f64_matches_reference(scenes, n):
     rays, xi, hits = fx.trace(n)
     got = scenes[n].trace_batch(rays, xi, abi.RT_PREC_F64)
@@ -66,7 +66,7 @@ def _check_f32_batch(name, sc, rays, xi, hits, got, min_same=0.99):
     return rows
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 4])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 6])
 def test_trace_batch_f32_close_to_reference(scenes, n):
     """Production arithmetic on ALL fixture rays (primary and secondary-like)."""
     rays, xi, hits = fx.trace(n)
@@ -121,7 +121,7 @@ def test_trace_batch_empty_and_ragged(scenes):
     assert (got["prim"] == hits["prim"][:257]).all()
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 4])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 6])
 def test_frame_f64_matches_oracle_path_for_path(scenes, n):
     sc = fx.scene(n)
     cam, _, _, _ = fx.img(n)
@@ -137,7 +137,7 @@ def test_frame_f64_matches_oracle_path_for_path(scenes, n):
     assert (O.write_color(acc.astype(np.float64), 1.0 / 16) == rgb).all()
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 4])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 6])
 def test_frame_f32_tracks_oracle(scenes, n):
     """float paths follow the double oracle's paths except where rounding flips a branch: most pixels agree to 1e-4."""
     sc = fx.scene(n)

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_CPP = "/root/reference/src/cpu/cpuRenderer.cpp"
 
 
-@pytest.mark.parametrize("n,name", [(1, "first_scene"), (2, "cornell_box"), (3, "final_scene"), (4, "mesh_scene")])
+@pytest.mark.parametrize("n,name", [(1, "first_scene"), (2, "cornell_box"), (3, "final_scene"), (4, "mesh_scene"), (6, "cornell_smoke")])
 def test_scene_api_builds_reference_graph_byte_for_byte(n, name):
     built = scenes.build(name, 64, 36, 9, 10)
     ref = fx.scene(n)

@@ -13,7 +13,7 @@ def _bytes_equal(a, b):
     return np.ascontiguousarray(a).tobytes() == np.ascontiguousarray(b).tobytes()
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 4])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 6])  # 6 = cornell smoke: constant_mediums bounded by boxes, instances, a moving sphere
 def test_trace_batch_bit_exact(n):
     sc = fx.scene(n)
     rays, xi, hits = fx.trace(n)
@@ -22,6 +22,9 @@ def test_trace_batch_bit_exact(n):
     for f in ("t", "p", "normal", "u", "v", "front_face"):
         assert _bytes_equal(got[f], hits[f]), f
     assert (hits["prim"] >= 0).sum() > 1000
+    if n == 6:
+        from raytracing_amd import abi
+        assert (sc.nodes["kind"][hits["prim"][hits["prim"] >= 0]] == abi.RT_NODE_MEDIUM).sum() > 200
 
 
 def test_box_corner_edge_batch_bit_exact():
@@ -55,7 +58,7 @@ def test_f32_bounds_module_agrees_with_the_reference_hits():
         assert all(r["status"] == "same" and r["rel_t"] == 0 and r["dn"] == 0 for r in rows)
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 4])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 6])
 def test_whole_frame_bit_exact(n):
     sc = fx.scene(n)
     cam, seed, sums, by = fx.img(n)

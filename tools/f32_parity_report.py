@@ -18,7 +18,7 @@ from tests import fixtures as fx  # noqa: E402
 ctx = lib.Context(0)
 os.makedirs("gpurun_out", exist_ok=True)
 report = {}
-for n in (1, 2, 3, 4, "box3"):
+for n in (1, 2, 3, 4, 6, "box3"):
     sc = fx.scene(3 if n == "box3" else n)
     ds = ctx.upload(sc)
     rays, xi, hits = fx.boxtrace(3) if n == "box3" else fx.trace(n)
