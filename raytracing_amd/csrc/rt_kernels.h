@@ -86,6 +86,10 @@ template <class R> RT_DEV V3<R> operator-(V3<R> a, V3<R> b) { return mk<R>(a.x -
 template <class R> RT_DEV V3<R> operator-(V3<R> a) { return mk<R>(-a.x, -a.y, -a.z); }
 template <class R> RT_DEV V3<R> operator*(V3<R> a, V3<R> b) { return mk<R>(a.x * b.x, a.y * b.y, a.z * b.z); }
 template <class R> RT_DEV V3<R> scale(R t, V3<R> v) { return mk<R>(t * v.x, t * v.y, t * v.z); }           // vec3.h:78
+// t * v + w, each component ONE expression: the float translation unit is built -ffp-contract=on, where the front end fuses
+// a * b + c within an expression and nothing else is ever fused -- every inlined copy of a routine then rounds alike
+// (see sphere_t) -- so the multiply-adds worth having are written as such.  (The double unit never fuses: reference order.)
+template <class R> RT_DEV V3<R> madd(R t, V3<R> v, V3<R> w) { return mk<R>(t * v.x + w.x, t * v.y + w.y, t * v.z + w.z); }
 // Division: the double path divides (reference arithmetic); the float path multiplies by v_rcp_f32 (1 ulp) -- hipcc's float
 // division is a 5-6 instruction sequence (frexp / rcp / ldexp range scaling) even without correct rounding.
 template <class R> RT_DEV R m_rcp(R x) {
@@ -107,10 +111,13 @@ template <class R> RT_DEV V3<R> unit(V3<R> v) { // vec3.h:102
     if constexpr (sizeof(R) == 4) return scale<R>(__builtin_amdgcn_rsqf(len2(v)), v);
     else return divide<R>(v, len(v));
 }
-template <class R> RT_DEV V3<R> reflect(V3<R> v, V3<R> n) { return v - scale<R>(R(2) * dot(v, n), n); }     // vec3.h:131
+template <class R> RT_DEV V3<R> reflect(V3<R> v, V3<R> n) {                                                   // vec3.h:131
+    if constexpr (sizeof(R) == 4) return madd<R>(R(-2) * dot(v, n), n, v);
+    else return v - scale<R>(R(2) * dot(v, n), n);
+}
 template <class R> RT_DEV V3<R> refract(V3<R> uv, V3<R> n, R etai_over_etat) {                              // vec3.h:135
     R cos_theta = m_min(dot(-uv, n), R(1));
-    V3<R> r_out_perp = scale<R>(etai_over_etat, uv + scale<R>(cos_theta, n));
+    V3<R> r_out_perp = scale<R>(etai_over_etat, sizeof(R) == 4 ? madd<R>(cos_theta, n, uv) : uv + scale<R>(cos_theta, n));
     V3<R> r_out_parallel = scale<R>(-m_sqrt(m_abs(R(1) - len2(r_out_perp))), n);
     return r_out_perp + r_out_parallel;
 }
@@ -119,7 +126,10 @@ template <class R> struct RayT { // ray.h:7 (direction is NOT normalised)
     V3<R> o, d;
     R tm;
 };
-template <class R> RT_DEV V3<R> ray_at(const RayT<R> &r, R t) { return r.o + scale<R>(t, r.d); } // ray.h:22
+template <class R> RT_DEV V3<R> ray_at(const RayT<R> &r, R t) { // ray.h:22
+    if constexpr (sizeof(R) == 4) return madd<R>(t, r.d, r.o);
+    else return r.o + scale<R>(t, r.d);
+}
 
 // ------------------------------------------------------------------------------------------------ RNG
 // Philox4x32-10, keyed by the 64-bit seed; counter = (block, sample, pixel, stream).  Identical to
@@ -326,21 +336,30 @@ RT_DEV bool aabox_t(const UnitT<R> &u0, const UnitT<R> &u1, V3<R> o, V3<R> inv, 
     return true;
 }
 
+// Float arithmetic with the fused multiply-adds WRITTEN OUT and no others formed (contract off): under -ffp-contract=fast
+// the compiler fuses each inlined COPY of a routine as it sees fit, and the same test then rounds differently in the
+// first and in the repeated step of a block's loop -- c = |oc|^2 - r^2 came out as fma in one copy and mul + sub in the
+// other, one ulp apart, times the cancellation of first_scene's r = 1000 ground.  Which copy a lane runs depends on the
+// wave's schedule, so frames did not repeat (values one float ulp apart, now and then a different ray count).
+RT_DEV float fdot3(V3<float> a, V3<float> b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+
 template <class R> RT_DEV bool sphere_t(V3<R> cc, R radius, V3<R> ro, V3<R> rd, R tmin, R tmax, R &t_out) { // sphere.h:29
-    V3<R> oc = cc - ro;
-    R a = len2(rd);
-    R h = dot(rd, oc);
-    R c = len2(oc) - radius * radius;
     if constexpr (sizeof(R) == 4) {
+#pragma clang fp contract(off)
         // Same quadratic, conditioned for float: h*h - a*c cancels catastrophically when |oc| >> radius (first_scene's
         // r=1 light 1000 units away, the r=1000 ground, final_scene's r=5000 fog).  disc = a*(r^2 - |oc - (h/a)d|^2) and
         // the roots c/q, q/a with q = h + sign(h)*sqrt(disc) are algebraically identical and lose no digits.
-        R inva = m_rcp(a);
-        V3<R> perp = oc - scale<R>(h * inva, rd);
-        R disc = a * (radius * radius - len2(perp));
+        const V3<R> oc = cc - ro;
+        const R a = fdot3(rd, rd);
+        const R h = fdot3(rd, oc);
+        const R c = __builtin_fmaf(-radius, radius, fdot3(oc, oc));
+        const R inva = m_rcp(a);
+        const R hia = h * inva;
+        const V3<R> perp = mk<R>(__builtin_fmaf(-hia, rd.x, oc.x), __builtin_fmaf(-hia, rd.y, oc.y), __builtin_fmaf(-hia, rd.z, oc.z));
+        const R disc = a * __builtin_fmaf(radius, radius, -fdot3(perp, perp));
         if (disc < R(0)) return false;
-        R sq = m_sqrt(disc);
-        R q = h + (h < R(0) ? -sq : sq);
+        const R sq = m_sqrt(disc);
+        const R q = h + (h < R(0) ? -sq : sq);
         R ta = m_div(c, q), tb = q * inva;
         R t0 = m_min(ta, tb), t1 = m_max(ta, tb);
         if (q == R(0)) { t0 = R(0); t1 = R(0); }
@@ -352,6 +371,10 @@ template <class R> RT_DEV bool sphere_t(V3<R> cc, R radius, V3<R> ro, V3<R> rd, 
         t_out = root;
         return true;
     } else {
+        V3<R> oc = cc - ro;
+        R a = len2(rd);
+        R h = dot(rd, oc);
+        R c = len2(oc) - radius * radius;
         R disc = h * h - a * c;
         if (disc < R(0)) return false;
         R sq = m_sqrt(disc);
@@ -840,7 +863,10 @@ template <class R> struct Onb { // onb.h:5
         v = unit(cross(w, a));
         u = cross(w, v);
     }
-    RT_DEV V3<R> transform(V3<R> q) const { return scale<R>(q.x, u) + scale<R>(q.y, v) + scale<R>(q.z, w); }
+    RT_DEV V3<R> transform(V3<R> q) const {
+        if constexpr (sizeof(R) == 4) return madd<R>(q.z, w, madd<R>(q.y, v, scale<R>(q.x, u)));
+        else return scale<R>(q.x, u) + scale<R>(q.y, v) + scale<R>(q.z, w);
+    }
 };
 
 // Draw orders below follow oracle/rt_oracle.cpp (which is pinned to the compiled reference): vec3::random(-1,1)

@@ -291,6 +291,27 @@ def make_boxtrace():
     print(f"boxtrace3: {len(rays)} rays, {(hits['prim'] >= 0).sum()} hits")
 
 
+def make_converged_square(s=2, side=50, seeds=(11, 12, 13, 14, 15)):
+    """cornell_box at 600x600 (BASELINE config C2) box-averaged 12x12 is the same integral as this 50x50 frame of the same
+    camera: 5 independent reference runs of 130^2 = 16 900 spp each (84 500 spp), depth 50."""
+    procs = [subprocess.Popen([os.path.join(REF, "refgen"), "render_nocheck", str(s), str(side), str(side), "16900", "50", "1",
+                               f"{OUT}/convsq_{s}_{k}.bin", str(k)], cwd=WORK, env=ENV, stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL) for k in seeds]
+    for p in procs:
+        assert p.wait() == 0
+    refgen("dump", s, side, side, 16900, 50, 1, f"{OUT}/scene{s}_sq.rtscene")
+    cam = abi.Scene.load(f"{OUT}/scene{s}_sq.rtscene").camera
+    tot, spp, runs = None, 0, []
+    for k in seeds:
+        W, H, n, d, seed, sums, by = read_img(f"{OUT}/convsq_{s}_{k}.bin")
+        runs.append(sums / (n * n))
+        tot = sums if tot is None else tot + sums
+        spp += n * n
+    np.savez_compressed(f"{GOLD}/conv{s}_sq.npz", camera=cam.view("u1"), mean=(tot / spp).astype(np.float64),
+                        spp=np.array([spp]), runs=np.stack(runs).astype(np.float32))
+    print(f"scene {s}: converged {side}x{side} fixture from {spp} spp")
+
+
 def make_extras():
     refgen("dump", 5, 64, 36, 9, 10, 1, f"{OUT}/scene5_f7.rtscene", 0, 7)
     abi.Scene.load(f"{OUT}/scene5_f7.rtscene").save_npz(f"{GOLD}/scene5_f7.npz")
@@ -310,6 +331,8 @@ def main():
     ap.add_argument("--png-only", action="store_true", help="only (re)generate the PNG decoding fixtures")
     ap.add_argument("--boxtrace-only", action="store_true", help="only (re)generate the box corner / edge ray batch")
     ap.add_argument("--smoke-only", action="store_true", help="only (re)generate scene 6 (cornell smoke: general medium boundaries)")
+    ap.add_argument("--converged-square", action="store_true",
+                    help="only: the converged 50x50 cornell_box frame (the 1:1 view of BASELINE config C2, 600x600)")
     a = ap.parse_args()
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
     os.makedirs(OUT, exist_ok=True)
@@ -321,6 +344,9 @@ def main():
         return
     if a.boxtrace_only:
         make_boxtrace()
+        return
+    if a.converged_square:
+        make_converged_square()
         return
     if a.smoke_only:
         a.scenes = "6"

@@ -96,3 +96,102 @@ def test_full_frame_downsampled_matches_converged_reference(headline, whole):
     floor = fx.psnr8(O.write_color(runs[:2].mean(axis=0).astype(np.float64), 1.0), O.write_color(runs[2:4].mean(axis=0).astype(np.float64), 1.0))
     print(f"1080p frame averaged to 48x27 vs converged reference: PSNR {psnr:.1f} dB (reference self-PSNR {floor:.1f} dB)")
     assert psnr >= 40.0
+
+
+# ---- the other BASELINE.json configurations at their full sizes --------------------------------------------------------------
+def _split_properties(ds, cam, n_ranks, seed):
+    """whole frame == sum of the per-rank stratum ranges (1 ulp of the total: each frame is its exact fixed-point sum
+    rounded to float once), identical ray counts, and a range repeats bit for bit.  Returns (whole, stats)."""
+    n = int(cam["sqrt_spp"][0])
+    Wc, Hc = int(cam["image_width"][0]), int(cam["image_height"][0])
+    whole, _, st = ds.render(cam, seed=seed, precision=abi.RT_PREC_F32, want_rgb8=False)
+    assert st["samples"] == Wc * Hc * n * n
+    total = np.zeros(whole.shape, dtype=np.float64)
+    rays = 0
+    for r in range(n_ranks):
+        s0, s1 = split_range(n * n, n_ranks, r)
+        part, _, pst = ds.render(cam, seed=seed, s_begin=s0, s_end=s1, precision=abi.RT_PREC_F32, want_rgb8=False)
+        total += part
+        rays += pst["rays"]
+        if r == n_ranks // 2:
+            again, _, ast = ds.render(cam, seed=seed, s_begin=s0, s_end=s1, precision=abi.RT_PREC_F32, want_rgb8=False)
+            assert ast["rays"] == pst["rays"] and again.tobytes() == part.tobytes(), "a rank's frame must repeat bit for bit"
+    assert rays == st["rays"], "same paths whatever the decomposition"
+    ok = np.isfinite(whole)
+    assert np.array_equal(ok, np.isfinite(total)) and (~ok).sum() <= 1e-4 * ok.size
+    np.testing.assert_allclose(total[ok], whole[ok].astype(np.float64), rtol=2.0 ** -23, atol=0)
+    return whole, st
+
+
+def _psnr_vs_converged(acc, n_strata, fixture, block):
+    cam_small, mean, _, runs = fixture
+    Hs, Ws = int(cam_small["image_height"][0]), int(cam_small["image_width"][0])
+    lin = np.nan_to_num(acc.astype(np.float64), nan=0.0, posinf=0.0, neginf=0.0) / n_strata
+    small = lin.reshape(Hs, block, Ws, block, 3).mean(axis=(1, 3))
+    psnr = fx.psnr8(O.write_color(small, 1.0), O.write_color(mean, 1.0))
+    floor = fx.psnr8(O.write_color(runs[:2].mean(axis=0).astype(np.float64), 1.0), O.write_color(runs[2:4].mean(axis=0).astype(np.float64), 1.0))
+    return psnr, floor
+
+
+def test_cornell_box_600x600_at_1000_spp(gpu_ctx):
+    """BASELINE config C2: cornell_box 600x600, 1000 spp (961 strata), depth 50, one GPU."""
+    scene = scn.build("cornell_box", 600, 600, 1000, 50)
+    ds = gpu_ctx.upload(scene)
+    try:
+        acc, st = _split_properties(ds, scene.camera, 8, seed=1984)
+        assert 4.5 <= st["rays"] / st["samples"] <= 5.7  # the reference traces 5.09 rays per sample here (SURVEY 8d)
+        c = fx.conv_square(2)
+        if c is None:
+            pytest.skip("converged 50x50 fixture not generated")
+        big, small = scene.camera, c[0]
+        np.testing.assert_allclose(small["center"][0], big["center"][0], rtol=0, atol=0)
+        np.testing.assert_allclose(small["pixel_delta_u"][0], 12 * big["pixel_delta_u"][0], rtol=1e-12, atol=1e-15)
+        psnr, floor = _psnr_vs_converged(acc, 961, c, 12)
+        print(f"cornell_box 600x600 averaged to 50x50 vs converged reference: PSNR {psnr:.1f} dB (reference self-PSNR {floor:.1f} dB)")
+        assert psnr >= 40.0
+    finally:
+        ds.close()
+
+
+def test_mesh_scene_1080p_at_500_spp(gpu_ctx):
+    """BASELINE config C3: mesh_scene (small_bunny.obj, 4 968 triangles; the stream does not fit LDS) 1920x1080, 500 spp
+    (484 strata), depth 50."""
+    scene = scn.build("mesh_scene", W, H, 500, DEPTH)
+    ds = gpu_ctx.upload(scene)
+    try:
+        assert int(scene.camera["sqrt_spp"][0]) == 22
+        acc, st = _split_properties(ds, scene.camera, 8, seed=1984)
+        assert 2.2 <= st["rays"] / st["samples"] <= 3.0  # reference: 2.59
+        c = fx.conv(4)
+        if c is None:
+            pytest.skip("converged fixture not generated")
+        psnr, floor = _psnr_vs_converged(acc, 484, c, 40)
+        print(f"mesh_scene 1080p averaged to 48x27 vs converged reference: PSNR {psnr:.1f} dB (reference self-PSNR {floor:.1f} dB)")
+        assert psnr >= 40.0
+    finally:
+        ds.close()
+
+
+@pytest.mark.parametrize("method,frame", [(0, 10), (1, 20), (2, 7)])
+def test_animation_frame_1080p(gpu_ctx, method, frame):
+    """BASELINE config C5: one 1080p frame of each animation sequence (rotate + zoom, translate, bounce) at 100 spp: the
+    frame a rank of 8 would own (frame f -> rank f mod 8), with the split / repeat properties of a still frame."""
+    from raytracing_amd import animation
+    from raytracing_amd.distributed import frame_shards
+    rank = frame % 8
+    assert frame in frame_shards(animation.n_frames(method), 8, rank)
+    found = None
+    for f, sc, cam in animation.frames(method, W, H, 100, DEPTH, rank=rank, world=8):
+        if f == frame:
+            found = (sc, cam)
+            break
+    assert found is not None
+    sc, cam = found
+    ds = gpu_ctx.upload(sc)
+    try:
+        acc, st = _split_properties(ds, cam, 4, seed=7)
+        assert st["samples"] == W * H * 100 and 5 <= st["rays"] / st["samples"] <= 40  # first_scene: ~20 rays per sample
+        lin = np.nan_to_num(acc) / 100.0
+        assert 0.2 < float(lin.mean()) < 1.5  # a lit sky-blue scene, not black, not saturated
+    finally:
+        ds.close()
