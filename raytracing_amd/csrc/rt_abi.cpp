@@ -319,7 +319,7 @@ int enqueue_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, int
 
 void print_profile(rt_ctx *ctx, const unsigned long long *c) { // diagnostic builds (-DRT_PROFILE_*) fill counters[3..39]
     if (std::getenv("RT_AMD_PROFILE_ACTIONS")) {
-        const char *nm[6] = {"box", "sphere", "aabox", "medium", "other", "shade"};
+        const char *nm[6] = {"box", "leaf", "-", "-", "-", "shade"};
         for (int k = 0; k < 6; k++)
             std::fprintf(stderr, "[rt_amd profile] %-6s cycles %.4g (%.1f%% of wave time) trips %.4g cyc/trip %.1f lanes/trip %.1f\n",
                          nm[k], (double)c[4 + 3 * k], 100.0 * (double)c[4 + 3 * k] / (double)(c[3] ? c[3] : 1), (double)c[5 + 3 * k],

@@ -1153,7 +1153,7 @@ enum : int { RT_MAX_SCHED_CHUNKS = 24 };
 #define RT_W_BOX 2
 #endif
 #ifndef RT_W_LEAF
-#define RT_W_LEAF 8
+#define RT_W_LEAF 3
 #endif
 #ifndef RT_SHADE_T
 #define RT_SHADE_T 40
@@ -1164,15 +1164,6 @@ enum : int { RT_MAX_SCHED_CHUNKS = 24 };
 #ifndef RT_BOX_REPEAT_MIN
 #define RT_BOX_REPEAT_MIN 8
 #endif
-#ifndef RT_LEAF_REPEAT // SPHERE / AABOX steps per trip while at least RT_LEAF_REPEAT_MIN lanes of the block stay at that kind
-#define RT_LEAF_REPEAT 2
-#endif
-#ifndef RT_LEAF_REPEAT_MIN
-#define RT_LEAF_REPEAT_MIN 4
-#endif
-#ifndef RT_OTHER_REPEAT // the same for the block of the rarer kinds (a box() is six quads in a row, a mesh leaf two triangles)
-#define RT_OTHER_REPEAT 1
-#endif
 struct RenderArgs {
     uint32_t k0, k1;
     int32_t s_begin, s_end;
@@ -1182,7 +1173,7 @@ struct RenderArgs {
     int32_t out_i64;         // float kernels: `out` receives 64-bit fixed-point cells (chunks summed afterwards), else floats
     int32_t chunk_start[RT_MAX_SCHED_CHUNKS + 1];        // decreasing-size schedule (chunk c = [chunk_start[c], chunk_start[c+1]))
 };
-enum : int { A_BOX = 0, A_SPHERE = 1, A_AABOX = 2, A_MEDIUM = 3, A_OTHER = 4, A_SHADE = 5, A_COUNT = 6, A_DEAL = 7 };
+enum : int { A_BOX = 0, A_LEAF = 1, A_SHADE = 5, A_COUNT = 6, A_DEAL = 7 };
 
 // Persistent megakernel.  A workgroup stages the scene stream into LDS once, then each of its waves pulls work items
 // (8x2 pixel tile x chunk of the stratified sample range) from a global cursor and deals the item's (pixel, sample)
@@ -1300,21 +1291,22 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             // number of waiting lanes (score = count * weight, block id in the low bits -> one max chain).
             const int nr = popc64(mr);
             int action = (mb | ms | ma | mm | mo | mr) ? A_SHADE : A_DEAL;
+            // (ONE leaf trip serves every lane that stands at a non-BOX record, each kind's code under its own mask: four
+            // blocks with 14 - 35 lanes each cost four trips' worth of selection and loop-join overhead; merged: 903 -> 884 ms)
+            const unsigned long long ml = ms | ma | mm | mo;
             if (nr < RT_SHADE_T) {
-                const unsigned sb = ((unsigned)(popc64(mb) * RT_W_BOX) << 3) | A_BOX, ss = ((unsigned)(popc64(ms) * RT_W_LEAF) << 3) | A_SPHERE,
-                               sa = ((unsigned)(popc64(ma) * RT_W_LEAF) << 3) | A_AABOX, sm = ((unsigned)(popc64(mm) * RT_W_LEAF) << 3) | A_MEDIUM,
-                               so = ((unsigned)(popc64(mo) * RT_W_LEAF) << 3) | A_OTHER;
-                const unsigned best = smax_u32(smax_u32(smax_u32(sb, ss), smax_u32(sa, sm)), so);
+                const unsigned sb = ((unsigned)(popc64(mb) * RT_W_BOX) << 3) | A_BOX, sl = ((unsigned)(popc64(ml) * RT_W_LEAF) << 3) | A_LEAF;
+                const unsigned best = smax_u32(sb, sl);
                 if (best >= 8u) action = (int)(best & 7u);
             }
+            const bool leaf_trip = action == A_LEAF;
 #ifdef RT_PROFILE_ACTIONS
             const unsigned long long t_a = __builtin_amdgcn_s_memtime();
             prof_idle += 64 - popc64(mb | ms | ma | mm | mo | mr);
             if (units_left <= 0) prof_tail += 1;
             prof_ready += nr;
             prof_all += 1;
-            const int n_act = action == A_BOX ? popc64(mb) : action == A_SPHERE ? popc64(ms) : action == A_AABOX ? popc64(ma)
-                              : action == A_MEDIUM ? popc64(mm) : action == A_OTHER ? popc64(mo) : nr;
+            const int n_act = action == A_BOX ? popc64(mb) : action == A_LEAF ? popc64(ml) : nr;
 #endif
             if (action == A_BOX) {
                 // a few BOX steps in a row while enough lanes stay at BOX records (amortises the block selection)
@@ -1327,34 +1319,26 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     at_box = h == make_hdr(K_BOX, 0);
                     if (popc64(lane_mask(at_box)) < RT_BOX_REPEAT_MIN) break;
                 }
-            } else if (action == A_SPHERE) {
-                // (the leaves of a BVH node are neighbours in the stream: a lane often meets two spheres in a row)
-                bool at = is_sph;
-                for (int rep = 0; rep < RT_LEAF_REPEAT; rep++) {
-                    if (at) {
-                        V3<R> cc = mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]);
-                        if constexpr (sizeof(R) == 8) cc = cc + scale<R>(ray.tm, mk<R>(R(0), R(0), R(0))); // center.at(time), sphere.h:30
-                        R t;
-                        if (sphere_t(cc, tv.u0.w[3], tv.o, tv.d, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx; }
-                        trav_goto(mem, tv, tv.i + 2);
-                    }
-                    int h = tv.hdr;
-                    at = at && (h & 15) == K_SPHERE;
-                    if (popc64(lane_mask(at)) < RT_LEAF_REPEAT_MIN) break;
+            }
+            // the leaf trip: one step of every kind that has lanes (a second step for lanes that meet the same kind again --
+            // the leaves of a BVH node are neighbours in the stream -- measured slower once the kinds share a trip)
+            if (leaf_trip && ms != 0ull) {
+                if (is_sph) {
+                    V3<R> cc = mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]);
+                    if constexpr (sizeof(R) == 8) cc = cc + scale<R>(ray.tm, mk<R>(R(0), R(0), R(0))); // center.at(time), sphere.h:30
+                    R t;
+                    if (sphere_t(cc, tv.u0.w[3], tv.o, tv.d, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx; }
+                    trav_goto(mem, tv, tv.i + 2);
                 }
-            } else if (action == A_AABOX) {
-                bool at = is_aab;
-                for (int rep = 0; rep < RT_LEAF_REPEAT; rep++) {
-                    if (at) {
-                        R t;
-                        if (aabox_t(tv.u0, tv.u1, tv.o, tv.inv, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx; }
-                        trav_goto(mem, tv, tv.i + 2);
-                    }
-                    int h = tv.hdr;
-                    at = at && (h & 15) == K_AABOX;
-                    if (popc64(lane_mask(at)) < RT_LEAF_REPEAT_MIN) break;
+            }
+            if (leaf_trip && ma != 0ull) {
+                if (is_aab) {
+                    R t;
+                    if (aabox_t(tv.u0, tv.u1, tv.o, tv.inv, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx; }
+                    trav_goto(mem, tv, tv.i + 2);
                 }
-            } else if (action == A_MEDIUM) {
+            }
+            if (leaf_trip && mm != 0ull) {
                 if (is_med) {
                     auto mxi = [&](int node_id) { return medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce); };
                     R t;
@@ -1364,18 +1348,14 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     }
                     trav_goto(mem, tv, tv.i + 2);
                 }
-            } else if (action == A_OTHER) {
-                bool at = is_oth;
-                for (int rep = 0; rep < RT_OTHER_REPEAT; rep++) {
-                    if (at) {
-                        auto mxi = [&](int node_id) { return medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce); };
-                        trav_leaf_step<GEN_MEDIUM>(mem, sc, tv, ray, tmin, mxi);
-                    }
-                    int h = tv.hdr;
-                    at = at && (h & 15) >= K_QUAD && (h & 15) < K_IDLE;
-                    if (popc64(lane_mask(at)) < RT_LEAF_REPEAT_MIN) break;
+            }
+            if (leaf_trip && mo != 0ull) {
+                if (is_oth) {
+                    auto mxi = [&](int node_id) { return medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce); };
+                    trav_leaf_step<GEN_MEDIUM>(mem, sc, tv, ray, tmin, mxi);
                 }
-            } else if (action == A_SHADE) {
+            }
+            if (action == A_SHADE) {
                 if (ready) {
 #ifdef RT_PROFILE_ACTIONS
                     sp.last = __builtin_amdgcn_s_memtime();
