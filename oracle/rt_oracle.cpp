@@ -83,10 +83,13 @@ struct Rec { // hittable.h:10
     }
 };
 
-// ---- Philox4x32-10 (Salmon et al., SC'11) : the counter-based RNG shared with the HIP kernels ----
-inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                          uint32_t out[4]) {
-    for (int r = 0; r < 10; r++) {
+// ---- Philox4x32 (Salmon et al., SC'11) : the counter-based RNG shared with the HIP kernels ----
+// The sample streams use SEVEN rounds (RT_STREAM_ROUNDS: the fewest the paper reports as Crush-resistant for 4x32; the
+// generator is 9 % of the GPU frame at ten); the ten-round function is kept for the Random123 known-answer vectors.
+enum { RT_STREAM_ROUNDS = 7 };
+inline void philox4x32(int rounds, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                       uint32_t out[4]) {
+    for (int r = 0; r < rounds; r++) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -98,6 +101,12 @@ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
         k1 += 0xBB67AE85u;
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    philox4x32(10, c0, c1, c2, c3, k0, k1, out);
+}
+inline void philox_stream(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    philox4x32(RT_STREAM_ROUNDS, c0, c1, c2, c3, k0, k1, out);
 }
 
 enum { RNG_GLIBC = 0, RNG_PHILOX = 1, RNG_INJECT = 2 };
@@ -111,7 +120,12 @@ struct Ctx {
     int mode;
     // philox state
     // counter = (block, sample, pixel, stream): stream 0 = the camera ray's draws (get_ray), 0x80000000|b = the draws of
-    // ray_color invocation b of the path (scatter + mixture pdf), 1+b = constant_medium draws (keyed by node id)
+    // ray_color invocation b of the path (scatter + mixture pdf).  A block is four 32-bit words = four uniforms, plus a
+    // FIFTH uniform of 24 bits made of the low bytes of words 0..2 (bits the float kernels' 24-bit uniforms never use):
+    // the fifth uniform of the block that starts ray b's predecessor -- the camera block for ray 0, bounce b-1's block 0
+    // otherwise -- serves the FIRST constant_medium that draws while ray b is traced (in final_scene: the fog, on every
+    // ray), so that draw costs no generator call; any further medium on the same ray draws from stream 1+b keyed by its
+    // node id.
     uint32_t k0 = 0, k1 = 0, pixel = 0, sample = 0, block = 0, have = 0, stream = 0;
     uint32_t buf[4];
     int bounce = 0;
@@ -120,14 +134,15 @@ struct Ctx {
     bool trace_keyed = false; // rt_trace_batch with xi == NULL
     Counters cnt;
 
+    bool med_fresh = false; // the ray being traced has not used its block's fifth uniform yet
     void begin_sample(uint32_t px, uint32_t s) { pixel = px; sample = s; block = 0; have = 0; stream = 0; }
-    void begin_bounce(int b) { block = 0; have = 0; stream = 0x80000000u | (uint32_t)b; }
+    void begin_bounce(int b) { block = 0; have = 0; stream = 0x80000000u | (uint32_t)b; med_fresh = true; }
 
     double next() { // utils.h:33 random_double()
         if (mode == RNG_GLIBC) return std::rand() / (RAND_MAX + 1.0);
         if (mode == RNG_INJECT) return inject;
         if (have == 0) {
-            philox4x32_10(block++, sample, pixel, stream, k0, k1, buf);
+            philox_stream(block++, sample, pixel, stream, k0, k1, buf);
             have = 4;
         }
         uint32_t x = buf[4 - have];
@@ -138,8 +153,16 @@ struct Ctx {
         if (mode == RNG_GLIBC) return std::rand() / (RAND_MAX + 1.0);
         if (mode == RNG_INJECT && !trace_keyed) return inject;
         uint32_t o[4];
-        if (trace_keyed) philox4x32_10((uint32_t)node_id, ray_lo, ray_hi, 0x7fffffffu, k0, k1, o);
-        else philox4x32_10((uint32_t)node_id, sample, pixel, 1u + (uint32_t)bounce, k0, k1, o);
+        if (trace_keyed) {
+            philox_stream((uint32_t)node_id, ray_lo, ray_hi, 0x7fffffffu, k0, k1, o);
+            return o[0] * (1.0 / 4294967296.0);
+        }
+        if (med_fresh) { // the fifth uniform of the block that started this ray's predecessor
+            med_fresh = false;
+            philox_stream(0u, sample, pixel, bounce == 0 ? 0u : (0x80000000u | (uint32_t)(bounce - 1)), k0, k1, o);
+            return (double)(((o[0] & 255u) << 16) | ((o[1] & 255u) << 8) | (o[2] & 255u)) * (1.0 / 16777216.0);
+        }
+        philox_stream((uint32_t)node_id, sample, pixel, 1u + (uint32_t)bounce, k0, k1, o);
         return o[0] * (1.0 / 4294967296.0);
     }
     double next(double mn, double mx) { return mn + (mx - mn) * next(); }          // utils.h:38

@@ -535,7 +535,10 @@ template <class R> class Flattener {
             f_.stream[self + 1] = UnitT<R>{{lo[2], hi[2], I(0), I(make_hdr(K_BOX, 0))}};
             int rc = emit(n.a, ctx, rdepth + 1);
             if (rc) return rc;
-            if (n.b != n.a) { // span-1 nodes have left == right (bvh.h:30): the second visit cannot change the result
+            // span-1 nodes have left == right (bvh.h:30) and the reference visits the child twice.  For geometry the second
+            // visit cannot change the result; a constant_medium draws a NEW uniform on it (constant_medium.h:41), i.e. the
+            // reference scatters in such a medium at the closer of two free paths -- so that child is emitted twice.
+            if (n.b != n.a || contains_medium(n.a, 0)) {
                 rc = emit(n.b, ctx, rdepth + 1);
                 if (rc) return rc;
             }

@@ -132,12 +132,12 @@ template <class R> RT_DEV V3<R> ray_at(const RayT<R> &r, R t) { // ray.h:22
 }
 
 // ------------------------------------------------------------------------------------------------ RNG
-// Philox4x32-10, keyed by the 64-bit seed; counter = (block, sample, pixel, stream).  Identical to
+// Philox4x32-7, keyed by the 64-bit seed; counter = (block, sample, pixel, stream).  Identical to
 // oracle/rt_oracle.cpp's so that f64 renders can be compared path by path.
-RT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t &o0,
+RT_DEV void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t &o0,
                           uint32_t &o1, uint32_t &o2, uint32_t &o3) {
-#ifndef RT_PHILOX_ROUNDS
-#define RT_PHILOX_ROUNDS 10
+#ifndef RT_PHILOX_ROUNDS // seven: the fewest rounds Salmon et al. report as Crush-resistant for Philox4x32 (ten: 9 % of the frame)
+#define RT_PHILOX_ROUNDS 7
 #endif
 #pragma unroll
     for (int r = 0; r < RT_PHILOX_ROUNDS; r++) {
@@ -159,14 +159,19 @@ template <> RT_DEV float u01<float>(uint32_t x) { return (x >> 8) * (1.0f / 1677
 
 // Stream protocol (shared with oracle/rt_oracle.cpp): counter = (block, sample, pixel, stream); stream 0 = the camera
 // ray's draws (get_ray), 0x80000000|b = the draws of ray_color invocation b of the path (scatter + mixture pdf),
-// 1+b = constant_medium draws keyed by node id.  begin*() computes block 0 unconditionally -- a wave-uniform point, so
-// the common case (<= 4 draws per bounce) never runs the generator under a divergent branch; no state survives a bounce.
+// 1+b = constant_medium draws keyed by node id -- except the FIRST medium that draws while ray b is traced: it takes the
+// fifth uniform (fifth()) of the block that started the ray's predecessor (camera block for ray 0, bounce b-1's block 0
+// otherwise), which the lane carries in `med_xi` (< 0 once used): final_scene's fog draws on every ray, and a generator
+// call per ray for it was 3 % of the frame.  begin*() computes block 0 unconditionally -- a wave-uniform point, so the
+// common case (<= 4 draws per bounce) never runs the generator under a divergent branch.
 template <class R> struct Rng {
     uint32_t k0, k1, pixel, sample, stream, block;
     uint32_t b0, b1, b2, b3;
     int have;
+    // the fifth uniform of the block just generated: the low bytes of words 0..2 (24 bits no float uniform uses)
+    RT_DEV R fifth() const { return R((int)(((b0 & 255u) << 16) | ((b1 & 255u) << 8) | (b2 & 255u))) * R(1.0 / 16777216.0); }
     RT_DEV void refill() {
-        philox4x32_10(block, sample, pixel, stream, k0, k1, b0, b1, b2, b3);
+        philox4x32(block, sample, pixel, stream, k0, k1, b0, b1, b2, b3);
         block++;
         have = 4;
     }
@@ -186,7 +191,7 @@ template <class R> struct Rng {
 // keyed draw for constant_medium.h:41
 template <class R> RT_DEV R medium_draw(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, int node_id, int bounce) {
     uint32_t o0, o1, o2, o3;
-    philox4x32_10((uint32_t)node_id, sample, pixel, 1u + (uint32_t)bounce, k0, k1, o0, o1, o2, o3);
+    philox4x32((uint32_t)node_id, sample, pixel, 1u + (uint32_t)bounce, k0, k1, o0, o1, o2, o3);
     return u01<R>(o0);
 }
 
@@ -1240,6 +1245,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     Trav<R> tv;
     tv.i = 0;
     tv.hdr = K_IDLE;
+    R med_xi = R(-1);   // the uniform for the first constant_medium that draws on this ray (< 0: used)
     int bounce = 0;     // index of the ray this lane traces within its path (0 = camera ray)
     int smp = 0;        // the unit this lane works on: sample index,
     int pp = 0;         //   pixel within the tile | accumulator slot << 6,
@@ -1340,7 +1346,12 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             }
             if (leaf_trip && mm != 0ull) {
                 if (is_med) {
-                    auto mxi = [&](int node_id) { return medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce); };
+                    auto mxi = [&](int node_id) {
+                        R x = med_xi;
+                        if (x < R(0)) x = medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce);
+                        med_xi = R(-1);
+                        return x;
+                    };
                     R t;
                     if (medium_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], tv.u1.w[0], ldi(tv.u1.w[2]), tv.o, tv.d, tmin,
                                  tv.best_t, mxi, t)) {
@@ -1351,7 +1362,12 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             }
             if (leaf_trip && mo != 0ull) {
                 if (is_oth) {
-                    auto mxi = [&](int node_id) { return medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce); };
+                    auto mxi = [&](int node_id) {
+                        R x = med_xi;
+                        if (x < R(0)) x = medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce);
+                        med_xi = R(-1);
+                        return x;
+                    };
                     trav_leaf_step<GEN_MEDIUM>(mem, sc, tv, ray, tmin, mxi);
                 }
             }
@@ -1364,6 +1380,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     g.k0 = a.k0;
                     g.k1 = a.k1;
                     g.begin_bounce(pixel, (uint32_t)smp, bounce);
+                    med_xi = g.fifth(); // for the ray this shading may start
                     RT_STAMP(0);
                     if constexpr (sizeof(R) == 4) { // traversal ended in the world frame: tv holds the world-space ray
                         ray.o = tv.o;
@@ -1489,6 +1506,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                                 g.k0 = a.k0;
                                 g.k1 = a.k1;
                                 g.begin(pixel, (uint32_t)smp);
+                                med_xi = g.fifth();
                                 ray = get_ray(cam, i, j, si, sj, g);
                                 beta = mk<R>(R(1), R(1), R(1));
                                 bounce = 0;
@@ -1568,7 +1586,7 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(SceneT<R> sc_arg, const rt
         auto mxi = [&](int node_id) {
             if (a.has_xi) return xik;
             uint32_t o0, o1, o2, o3;
-            philox4x32_10((uint32_t)node_id, (uint32_t)k, (uint32_t)((uint64_t)k >> 32), 0x7fffffffu, a.k0, a.k1, o0, o1, o2, o3);
+            philox4x32((uint32_t)node_id, (uint32_t)k, (uint32_t)((uint64_t)k >> 32), 0x7fffffffu, a.k0, a.k1, o0, o1, o2, o3);
             return u01<R>(o0);
         };
         Trav<R> tv;

@@ -10,7 +10,7 @@ best = 1e9
 for rep in range(2):
     _, _, st = ds.render(scene.camera, seed=1, s_begin=0, s_end=int(os.environ.get("S_END", "-1")), precision=abi.RT_PREC_F32, want_rgb8=False)
     best = min(best, st["kernel_ms"])
-print(f"{best:.1f} ms  {st['samples']/best/1e3:.1f} Msamples/s", flush=True)
+print(f"{best:.1f} ms  {st['samples']/best/1e3:.1f} Msamples/s  rays/sample {st['rays']/st['samples']:.4f}", flush=True)
 '''
 for spec in sys.argv[1:]:
     parts = spec.split(":")
