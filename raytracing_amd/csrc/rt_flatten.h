@@ -86,7 +86,7 @@ template <class R> class Flattener {
         // transform context of its medium and with a sentinel of its own (constant_medium.h:24-28 runs boundary->hit twice)
         for (size_t k = 0; k < pending_.size(); k++) {
             const Pending pd = pending_[k];
-            f_.stream[pd.record].w[0] = I((int)f_.stream.size());
+            f_.stream[pd.record].w[0] = I(pos());
             rc = emit(pd.boundary, pd.ctx, 0);
             if (rc) return rc;
             const int e2 = push_units(2, -1);
@@ -106,7 +106,8 @@ template <class R> class Flattener {
     };
     std::vector<Pending> pending_;
     double box_pad_ = 0; // float streams: see run()
-    static constexpr size_t kMaxUnits = size_t(1) << 26;
+    static constexpr size_t kMaxUnits = size_t(1) << 25; // positions are byte offsets in an int
+    int pos() const { return (int)(f_.stream.size() * sizeof(UnitT<R>)); } // where the next record will stand
 
     int fail(int code, const std::string &msg) {
         err_ = msg;
@@ -465,7 +466,7 @@ template <class R> class Flattener {
                 cvt_hi(hi[a] + pad, rh[a]);
             }
             f_.stream[self] = UnitT<R>{{rl[0], rh[0], rl[1], rh[1]}};
-            f_.stream[self + 1] = UnitT<R>{{rl[2], rh[2], I((int)f_.stream.size()), I(make_hdr(K_BOX, 0))}};
+            f_.stream[self + 1] = UnitT<R>{{rl[2], rh[2], I(pos()), I(make_hdr(K_BOX, 0))}};
             return RT_OK;
         }
         case RT_NODE_LIST:
@@ -542,7 +543,7 @@ template <class R> class Flattener {
                 rc = emit(n.b, ctx, rdepth + 1);
                 if (rc) return rc;
             }
-            f_.stream[self + 1].w[2] = I((int)f_.stream.size());
+            f_.stream[self + 1].w[2] = I(pos());
             return RT_OK;
         }
         case RT_NODE_LIST: { // hittable_list.h:29: children in insertion order, each against the closest hit so far

@@ -215,25 +215,33 @@ RT_DEV UnitT<double> ld_unit(const UnitT<double> *p) {
     return UnitT<double>{{a.x, a.y, b.x, b.y}};
 }
 
+// Positions in the stream are BYTE offsets (cursor, skip links, the winning record): a unit's LDS address is then the
+// position plus a constant, with no shift in the hot BOX step.
+template <class R> struct Pos {
+    static constexpr int unit = (int)sizeof(UnitT<R>);
+};
 template <class R, bool ALL_LDS> struct Mem {
     const UnitT<R> *glob;
-    int lds_units;
-    RT_DEV UnitT<R> ld(int off) const {
-        const UnitT<R> *l = reinterpret_cast<const UnitT<R> *>(rt_smem + LdsLayout<R>::stream_off);
+    int lds_bytes;
+    RT_DEV UnitT<R> ld(int pos) const {
+        const unsigned char *l = rt_smem + LdsLayout<R>::stream_off;
         if constexpr (ALL_LDS) {
-            return ld_unit(l + off);
+            return ld_unit(reinterpret_cast<const UnitT<R> *>(l + pos));
         } else {
             UnitT<R> u;
-            if (off < lds_units) {
-                u = ld_unit(l + off);
+            if (pos < lds_bytes) {
+                u = ld_unit(reinterpret_cast<const UnitT<R> *>(l + pos));
             } else {
-                asm volatile("" : "+v"(off)); // keep the two address spaces in separate blocks (no pointer select -> flat load)
-                u = ld_unit(glob + off);
+                asm volatile("" : "+v"(pos)); // keep the two address spaces in separate blocks (no pointer select -> flat load)
+                u = ld_unit(reinterpret_cast<const UnitT<R> *>(reinterpret_cast<const unsigned char *>(glob) + pos));
             }
             return u;
         }
     }
 };
+template <class R> RT_DEV UnitT<R> cold_at(const UnitT<R> *cold, int pos) {
+    return *reinterpret_cast<const UnitT<R> *>(reinterpret_cast<const unsigned char *>(cold) + pos);
+}
 
 // What the kernels see of the scene's shading tables.  TAB_LDS: the tables were staged into LDS behind the stream and are
 // addressed as offsets into rt_smem, so the lookups compile to ds_read (a pointer that may be LDS or global would make
@@ -526,10 +534,10 @@ template <class R> struct Trav {
     V3<R> o, d, inv; // ray in the space of context `ctx`
     V3<R> noi;       // float path: -o * inv, so that a slab distance is one fma (b * inv + noi)
     R best_t;
-    int best_off; // stream offset of the winning record, -1 = miss
+    int best_off; // position (byte offset) of the winning record, -1 = miss
     int best_ctx;
     int ctx;
-    int i; // cursor (unit offset)
+    int i; // cursor (byte offset of the record)
     // the record at the cursor
     UnitT<R> u0, u1;
     int hdr;
@@ -540,7 +548,7 @@ template <class R> struct Trav {
 template <class R, bool ALL_LDS> RT_DEV void trav_goto(const Mem<R, ALL_LDS> &mem, Trav<R> &tv, int i) {
     tv.i = i;
     tv.u0 = mem.ld(i);
-    tv.u1 = mem.ld(i + 1);
+    tv.u1 = mem.ld(i + Pos<R>::unit);
     tv.hdr = ldi(tv.u1.w[3]);
 }
 
@@ -561,7 +569,7 @@ RT_DEV void trav_begin(const Mem<R, ALL_LDS> &mem, Trav<R> &tv, const RayT<R> &w
 template <class R, bool ALL_LDS>
 RT_DEV void trav_box_step(const Mem<R, ALL_LDS> &mem, Trav<R> &tv, R tmin) {
     const bool hit = box_hit(tv.u0, tv.u1, tv.o, tv.inv, tv.noi, tmin, tv.best_t);
-    trav_goto(mem, tv, hit ? tv.i + 2 : ldi(tv.u1.w[2]));
+    trav_goto(mem, tv, hit ? tv.i + 2 * Pos<R>::unit : ldi(tv.u1.w[2]));
 }
 
 // One non-BOX record.  GM: the stream may hold MEDIUM_GEN records (a constant_medium whose boundary is a sub-stream).
@@ -569,14 +577,15 @@ template <bool GM, class R, bool ALL_LDS, class SC, class MediumXi>
 RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SC &sc, Trav<R> &tv, const RayT<R> &world, R tmin,
                            MediumXi medium_xi) {
     const int kind = tv.hdr & 15;
+    constexpr int U = Pos<R>::unit;
     const int i = tv.i;
-    int next = i + 2;
+    int next = i + 2 * U;
     if (kind == K_SPHERE || kind == K_MSPHERE) {
         V3<R> cc = mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]);
         if (kind == K_MSPHERE) { // moving sphere: centre = c + time*d (sphere.h:30)
-            const UnitT<R> u2 = mem.ld(i + 2);
+            const UnitT<R> u2 = mem.ld(i + 2 * U);
             cc = cc + scale<R>(world.tm, mk<R>(u2.w[0], u2.w[1], u2.w[2]));
-            next = i + 3;
+            next = i + 3 * U;
         } else if constexpr (sizeof(R) == 8) {
             cc = cc + scale<R>(world.tm, mk<R>(R(0), R(0), R(0))); // the reference always evaluates center.at(time)
         }
@@ -586,23 +595,23 @@ RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SC &sc, Trav<R> &tv
         R t;
         if (aabox_t(tv.u0, tv.u1, tv.o, tv.inv, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = i; tv.best_ctx = tv.ctx; }
     } else if (kind == K_QUAD) {
-        const UnitT<R> u2 = mem.ld(i + 2), u3 = mem.ld(i + 3), u4 = mem.ld(i + 4);
+        const UnitT<R> u2 = mem.ld(i + 2 * U), u3 = mem.ld(i + 3 * U), u4 = mem.ld(i + 4 * U);
         R t, al, be;
         if (quad_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], mk<R>(tv.u1.w[0], tv.u1.w[1], tv.u1.w[2]),
                    mk<R>(u2.w[0], u2.w[1], u2.w[2]), mk<R>(u3.w[0], u3.w[1], u3.w[2]), mk<R>(u4.w[0], u4.w[1], u4.w[2]), tv.o, tv.d,
                    tmin, tv.best_t, t, al, be)) {
             tv.best_t = t; tv.best_off = i; tv.best_ctx = tv.ctx;
         }
-        next = i + 5;
+        next = i + 5 * U;
     } else if (kind == K_TRI) {
-        const UnitT<R> u2 = mem.ld(i + 2);
+        const UnitT<R> u2 = mem.ld(i + 2 * U);
         R t;
         float u, v;
         if (tri_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), mk<R>(tv.u0.w[3], tv.u1.w[0], tv.u1.w[1]),
                   mk<R>(tv.u1.w[2], u2.w[0], u2.w[1]), ldi(u2.w[3]), tv.o, tv.d, tmin, tv.best_t, t, u, v)) {
             tv.best_t = t; tv.best_off = i; tv.best_ctx = tv.ctx;
         }
-        next = i + 3;
+        next = i + 3 * U;
     } else if (kind == K_MEDIUM) {
         R t;
         if (medium_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], tv.u1.w[0], ldi(tv.u1.w[2]), tv.o, tv.d, tmin,
@@ -690,7 +699,8 @@ RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SC &sc, const RayT<R> &
     h.u = R(0);
     h.v = R(0);
     h.prim = -1;
-    const UnitT<R> u0 = mem.ld(best_off), u1 = mem.ld(best_off + 1);
+    constexpr int U = Pos<R>::unit;
+    const UnitT<R> u0 = mem.ld(best_off), u1 = mem.ld(best_off + U);
     const int hdr = ldi(u1.w[3]);
     h.kind = hdr & 15;
     const RayT<R> r = ray_in_ctx(sc, world, best_ctx);
@@ -698,7 +708,7 @@ RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SC &sc, const RayT<R> &
     if (h.kind == K_SPHERE || h.kind == K_MSPHERE) {
         V3<R> cc = mk<R>(u0.w[0], u0.w[1], u0.w[2]);
         if (h.kind == K_MSPHERE) {
-            const UnitT<R> u2 = mem.ld(best_off + 2);
+            const UnitT<R> u2 = mem.ld(best_off + 2 * U);
             cc = cc + scale<R>(r.tm, mk<R>(u2.w[0], u2.w[1], u2.w[2]));
         } else if constexpr (sizeof(R) == 8) {
             cc = cc + scale<R>(r.tm, mk<R>(R(0), R(0), R(0)));
@@ -708,7 +718,7 @@ RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SC &sc, const RayT<R> &
         h.n = h.front ? outward : -outward;
         h.mat = ldi(u1.w[0]);
         if (want_all || sc.mat(h.mat).needs_uv) sphere_uv(outward, h.u, h.v);
-        if (want_all) h.prim = ldi(sc.cold[best_off].w[3]);
+        if (want_all) h.prim = ldi(cold_at(sc.cold, best_off).w[3]);
     } else if (h.kind == K_AABOX) {
         // which face: the slab plane whose distance is the winning t
         const V3<R> inv = inv_dir(r.d);
@@ -733,12 +743,12 @@ RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SC &sc, const RayT<R> &
         h.n = h.front ? n : -n;
         h.mat = ldi(u1.w[2]);
         if (want_all) {
-            const UnitT<R> c = sc.cold[best_off + (face >> 2)];
+            const UnitT<R> c = cold_at(sc.cold, best_off + (face >> 2) * U);
             const int k = face & 3;
             h.prim = ldi(k == 0 ? c.w[0] : (k == 1 ? c.w[1] : (k == 2 ? c.w[2] : c.w[3])));
         }
     } else if (h.kind == K_QUAD) {
-        const UnitT<R> u2 = mem.ld(best_off + 2), u3 = mem.ld(best_off + 3), u4 = mem.ld(best_off + 4);
+        const UnitT<R> u2 = mem.ld(best_off + 2 * U), u3 = mem.ld(best_off + 3 * U), u4 = mem.ld(best_off + 4 * U);
         V3<R> ph = h.p - mk<R>(u1.w[0], u1.w[1], u1.w[2]);
         V3<R> w = mk<R>(u4.w[0], u4.w[1], u4.w[2]);
         h.u = dot(w, cross(ph, mk<R>(u3.w[0], u3.w[1], u3.w[2])));
@@ -747,16 +757,16 @@ RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SC &sc, const RayT<R> &
         h.front = dot(r.d, n) < R(0);
         h.n = h.front ? n : -n;
         h.mat = ldi(u2.w[3]);
-        if (want_all) h.prim = ldi(sc.cold[best_off].w[3]);
+        if (want_all) h.prim = ldi(cold_at(sc.cold, best_off).w[3]);
     } else if (h.kind == K_TRI) {
-        const UnitT<R> u2 = mem.ld(best_off + 2);
+        const UnitT<R> u2 = mem.ld(best_off + 2 * U);
         R t;
         float u = 0.f, v = 0.f;
         tri_t(mk<R>(u0.w[0], u0.w[1], u0.w[2]), mk<R>(u0.w[3], u1.w[0], u1.w[1]), mk<R>(u1.w[2], u2.w[0], u2.w[1]), ldi(u2.w[3]),
               r.o, r.d, -Const<R>::inf, Const<R>::inf, t, u, v);
         h.u = R(u);
         h.v = R(v);
-        const UnitT<R> c = sc.cold[best_off];
+        const UnitT<R> c = cold_at(sc.cold, best_off);
         V3<R> n = mk<R>(c.w[0], c.w[1], c.w[2]);
         h.front = dot(r.d, n) < R(0);
         h.n = h.front ? n : -n;
@@ -1212,7 +1222,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
         RT_OWN(cam.background[k]);
     }
 #undef RT_OWN
-    const Mem<R, ALL_LDS> mem{sc_arg.stream, sc_arg.lds_units};
+    const Mem<R, ALL_LDS> mem{sc_arg.stream, sc_arg.lds_units * Pos<R>::unit};
     const int lane = threadIdx.x & 63;
     const R tmin = R(0.001);
     // this wave's accumulators (item_slots slots = items in flight, x tile_px pixels x RGB) and item state
@@ -1334,14 +1344,14 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     if constexpr (sizeof(R) == 8) cc = cc + scale<R>(ray.tm, mk<R>(R(0), R(0), R(0))); // center.at(time), sphere.h:30
                     R t;
                     if (sphere_t(cc, tv.u0.w[3], tv.o, tv.d, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx; }
-                    trav_goto(mem, tv, tv.i + 2);
+                    trav_goto(mem, tv, tv.i + 2 * Pos<R>::unit);
                 }
             }
             if (leaf_trip && ma != 0ull) {
                 if (is_aab) {
                     R t;
                     if (aabox_t(tv.u0, tv.u1, tv.o, tv.inv, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx; }
-                    trav_goto(mem, tv, tv.i + 2);
+                    trav_goto(mem, tv, tv.i + 2 * Pos<R>::unit);
                 }
             }
             if (leaf_trip && mm != 0ull) {
@@ -1357,7 +1367,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                                  tv.best_t, mxi, t)) {
                         tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx;
                     }
-                    trav_goto(mem, tv, tv.i + 2);
+                    trav_goto(mem, tv, tv.i + 2 * Pos<R>::unit);
                 }
             }
             if (leaf_trip && mo != 0ull) {
@@ -1576,7 +1586,7 @@ template <class R, bool ALL_LDS, bool TAB_LDS, bool GEN_MEDIUM, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) trace_kernel(SceneT<R> sc_arg, const rt_ray *__restrict__ rays, const double *__restrict__ xi,
                                                       size_t n, rt_hit *__restrict__ out, TraceArgs a) {
     const SceneV<R, TAB_LDS> sc = stage_scene<R, TAB_LDS>(sc_arg);
-    const Mem<R, ALL_LDS> mem{sc_arg.stream, sc_arg.lds_units};
+    const Mem<R, ALL_LDS> mem{sc_arg.stream, sc_arg.lds_units * Pos<R>::unit};
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
         RayT<R> r;
         r.o = mk<R>(R(rays[k].orig[0]), R(rays[k].orig[1]), R(rays[k].orig[2]));

@@ -13,7 +13,8 @@
 // workgroup; the remainder (large meshes) is read from global memory through L1/L2.
 //
 //   record            units  unit0                     unit1                              unit2..
-//   BOX     (bvh_node)   2   x.min, x.max, y.min, y.max   z.min, z.max, skip, hdr          (min/max pairs: packed f32 math)
+//   BOX     (bvh_node)   2   x.min, x.max, y.min, y.max   z.min, z.max, skip, hdr          (min/max pairs: packed f32 math;
+//                                                                                         skip = BYTE offset of the record behind the subtree)
 //   SPHERE / MSPHERE     2/3 c.xyz, radius             mat, -, -, hdr                     d.xyz (MSPHERE: centre = c + time*d)
 //   AABOX   (box())      2   x.min, x.max, y.min, y.max   z.min, z.max, mat, hdr(payload = 6 face-orientation bits)
 //   QUAD                 5   n.xyz, D                  Q.xyz, hdr                         u.xyz, mat | v.xyz, area | w.xyz, -
