@@ -238,6 +238,13 @@ int rt_scene_info(const rt_scene *scene, int32_t *out);
  * Returns RT_OK or the status rt_scene_upload would return for this description.  No reference counterpart. */
 int rt_scene_flatten_info(const rt_scene_desc *desc, int32_t *out);
 
+/* Host-only (no GPU, no context): the f32 (production) record stream rt_scene_upload would put on the device, for
+ * structure tests and traversal statistics: 16-byte units of four 32-bit words (layout: raytracing_amd/csrc/rt_scene.h).
+ * Copies at most `cap_units` units into `units` (may be NULL with cap_units 0) and the description node id of the
+ * record that starts at each unit (or -1) into `node_ids` (may be NULL); *n_units = size of the whole stream.
+ * No reference counterpart. */
+int rt_scene_flatten_stream(const rt_scene_desc *desc, void *units, int32_t *node_ids, size_t cap_units, size_t *n_units);
+
 /* Closest hit of each ray in [0.001, inf): replaces world.hit(r, interval(0.001, infinity), rec)
  * (camera.h:300 -> hittable_list.h:24 / bvh.h:43).  `xi` (optional, one per ray) is the uniform every
  * constant_medium on that ray consumes (constant_medium.h:41); NULL = counter-based RNG keyed by ray index.

@@ -123,9 +123,14 @@ struct Ctx {
     // ray_color invocation b of the path (scatter + mixture pdf).  A block is four 32-bit words = four uniforms, plus a
     // FIFTH uniform of 24 bits made of the low bytes of words 0..2 (bits the float kernels' 24-bit uniforms never use):
     // the fifth uniform of the block that starts ray b's predecessor -- the camera block for ray 0, bounce b-1's block 0
-    // otherwise -- serves the FIRST constant_medium that draws while ray b is traced (in final_scene: the fog, on every
-    // ray), so that draw costs no generator call; any further medium on the same ray draws from stream 1+b keyed by its
-    // node id.
+    // otherwise -- serves the scene's PRIMARY constant_medium while ray b is traced (primary_medium() below: the medium
+    // with the largest boundary box; in final_scene the fog, which draws on every ray), so that draw costs no generator
+    // call.  Every other medium draws from stream 1+b keyed by its node id.  Which uniform a medium gets therefore does
+    // not depend on the order in which a ray meets the scene's objects (the production path walks a bounding-volume
+    // hierarchy of its own).  A span-1 bvh_node has left == right (bvh.h:30) and the reference hits that child twice, a
+    // constant_medium below it drawing a fresh uniform each time: `dup` is the path of second visits above the current
+    // node (2*dup for the first visit, 2*dup+1 for the second); only visit 0 of the primary medium takes the fifth
+    // uniform, any other visit is keyed by (node id, dup).
     uint32_t k0 = 0, k1 = 0, pixel = 0, sample = 0, block = 0, have = 0, stream = 0;
     uint32_t buf[4];
     int bounce = 0;
@@ -134,9 +139,10 @@ struct Ctx {
     bool trace_keyed = false; // rt_trace_batch with xi == NULL
     Counters cnt;
 
-    bool med_fresh = false; // the ray being traced has not used its block's fifth uniform yet
+    int primary = -1;  // primary_medium(sc)
+    uint32_t dup = 0;  // second-visit path of span-1 bvh_nodes above the node being hit
     void begin_sample(uint32_t px, uint32_t s) { pixel = px; sample = s; block = 0; have = 0; stream = 0; }
-    void begin_bounce(int b) { block = 0; have = 0; stream = 0x80000000u | (uint32_t)b; med_fresh = true; }
+    void begin_bounce(int b) { block = 0; have = 0; stream = 0x80000000u | (uint32_t)b; }
 
     double next() { // utils.h:33 random_double()
         if (mode == RNG_GLIBC) return std::rand() / (RAND_MAX + 1.0);
@@ -154,15 +160,14 @@ struct Ctx {
         if (mode == RNG_INJECT && !trace_keyed) return inject;
         uint32_t o[4];
         if (trace_keyed) {
-            philox_stream((uint32_t)node_id, ray_lo, ray_hi, 0x7fffffffu, k0, k1, o);
+            philox_stream((uint32_t)node_id, ray_lo, ray_hi, 0x7fffffffu - dup, k0, k1, o);
             return o[0] * (1.0 / 4294967296.0);
         }
-        if (med_fresh) { // the fifth uniform of the block that started this ray's predecessor
-            med_fresh = false;
+        if (node_id == primary && dup == 0) { // the fifth uniform of the block that started this ray's predecessor
             philox_stream(0u, sample, pixel, bounce == 0 ? 0u : (0x80000000u | (uint32_t)(bounce - 1)), k0, k1, o);
             return (double)(((o[0] & 255u) << 16) | ((o[1] & 255u) << 8) | (o[2] & 255u)) * (1.0 / 16777216.0);
         }
-        philox_stream((uint32_t)node_id, sample, pixel, 1u + (uint32_t)bounce, k0, k1, o);
+        philox_stream((uint32_t)node_id, sample, pixel, 1u + (uint32_t)bounce + (dup << 16), k0, k1, o);
         return o[0] * (1.0 / 4294967296.0);
     }
     double next(double mn, double mx) { return mn + (mx - mn) * next(); }          // utils.h:38
@@ -339,6 +344,22 @@ bool triangle_hit(const rt_triangle &tr, int node, const Ray &r, Interval ray_t,
 
 bool node_hit(int id, const Ray &r, Interval ray_t, Rec &rec, Ctx &c);
 
+// The constant_medium that takes the fifth uniform (see Ctx): the one whose boundary has the bounding box of largest
+// surface area, the lowest node id among equals; -1 if the scene has none.
+int primary_medium(const rt_scene_desc *sc) {
+    int best = -1;
+    double best_area = -1.0;
+    for (int i = 0; i < sc->n_nodes; i++) {
+        const rt_node &n = sc->nodes[i];
+        if (n.kind != RT_NODE_MEDIUM || n.a < 0 || n.a >= sc->n_nodes) continue;
+        const double *b = sc->nodes[n.a].bbox;
+        const double dx = b[1] - b[0], dy = b[3] - b[2], dz = b[5] - b[4];
+        const double area = 2.0 * (dx * dy + dy * dz + dz * dx);
+        if (area > best_area) { best_area = area; best = i; }
+    }
+    return best;
+}
+
 bool medium_hit(const rt_node &n, int node, const Ray &r, Interval ray_t, Rec &rec, Ctx &c) { // constant_medium.h:21
     Rec rec1, rec2;
     if (!node_hit(n.a, r, Interval{-infinity, infinity}, rec1, c)) return false;
@@ -366,8 +387,12 @@ bool node_hit(int id, const Ray &r, Interval ray_t, Rec &rec, Ctx &c) {
     switch (n.kind) {
     case RT_NODE_BVH: { // bvh.h:43
         if (!aabb_hit(n.bbox, r, ray_t, c)) return false;
+        const uint32_t dup = c.dup;
+        if (n.a == n.b) c.dup = 2 * dup; // span 1: the same child twice (see Ctx)
         bool hit_left = node_hit(n.a, r, ray_t, rec, c);
+        if (n.a == n.b) c.dup = 2 * dup + 1;
         bool hit_right = node_hit(n.b, r, Interval{ray_t.min, hit_left ? rec.t : ray_t.max}, rec, c);
+        c.dup = dup;
         return hit_left || hit_right;
     }
     case RT_NODE_LIST: { // hittable_list.h:24
@@ -699,6 +724,7 @@ int orc_trace_batch(const rt_scene_desc *sc, const rt_ray *rays, const double *x
                     uint64_t *counters /* optional [5]: aabb,sphere,quad,tri,rays */) {
     Ctx c;
     c.sc = sc;
+    c.primary = primary_medium(sc);
     c.mode = RNG_INJECT;
     c.trace_keyed = (xi == nullptr);
     for (size_t k = 0; k < n; k++) {
@@ -750,6 +776,7 @@ int orc_render(const rt_scene_desc *sc, const rt_camera *cam, uint64_t seed, int
     for (int j = 0; j < H; j++) {
         Ctx c;
         c.sc = sc;
+        c.primary = primary_medium(sc);
         c.mode = rng_mode;
         c.k0 = (uint32_t)seed;
         c.k1 = (uint32_t)(seed >> 32);

@@ -136,7 +136,8 @@ template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, Device
     const double t0 = wall_ms();
     Flat<R> f;
     std::string err;
-    Flattener<R> fl(*desc, f, err, /*fuse_boxes=*/sizeof(R) == 4);
+    // RT_AMD_REF_ORDER (development knob): the float stream keeps the reference's bvh_nodes and visiting order
+    Flattener<R> fl(*desc, f, err, /*fuse_boxes=*/sizeof(R) == 4, /*own_hierarchy=*/sizeof(R) == 4 && !std::getenv("RT_AMD_REF_ORDER"));
     int rc = fl.run();
     if (rc) return set_err(ctx, rc, err);
     BlobBuilder b;
@@ -471,11 +472,25 @@ int rt_scene_info(const rt_scene *scene, int32_t *out /* [4]: flat nodes, lights
     return RT_OK;
 }
 
+int rt_scene_flatten_stream(const rt_scene_desc *desc, void *units, int32_t *node_ids, size_t cap_units, size_t *n_units) {
+    if (!desc || !n_units || (cap_units > 0 && !units)) return RT_ERR_INVALID;
+    std::string err;
+    Flat<float> f;
+    int rc = Flattener<float>(*desc, f, err, true, !std::getenv("RT_AMD_REF_ORDER")).run();
+    if (rc) return rc;
+    *n_units = f.stream.size();
+    const size_t n = std::min(cap_units, f.stream.size());
+    if (n) std::memcpy(units, f.stream.data(), n * sizeof(UnitT<float>));
+    if (node_ids)
+        for (size_t k = 0; k < n; k++) node_ids[k] = dec_int(f.cold[k].w[3]);
+    return RT_OK;
+}
+
 int rt_scene_flatten_info(const rt_scene_desc *desc, int32_t *out) {
     if (!desc || !out) return RT_ERR_INVALID;
     std::string err;
     Flat<float> f32;
-    int rc = Flattener<float>(*desc, f32, err, true).run();
+    int rc = Flattener<float>(*desc, f32, err, true, !std::getenv("RT_AMD_REF_ORDER")).run();
     if (rc) return rc;
     Flat<double> f64;
     rc = Flattener<double>(*desc, f64, err, false).run();

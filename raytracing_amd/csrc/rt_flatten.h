@@ -3,8 +3,10 @@
 #ifndef RT_FLATTEN_H
 #define RT_FLATTEN_H
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <numeric>
 #include <string>
 #include <utility>
 #include <vector>
@@ -52,8 +54,10 @@ template <class R> class Flattener {
   public:
     // fuse_boxes: replace a hittable_list of six axis-aligned quads forming a closed box (quad.h:103 box()) by one
     // AABOX record.  Used for the f32 stream only; the f64 parity stream keeps the reference's six quads.
-    Flattener(const rt_scene_desc &d, Flat<R> &out, std::string &err, bool fuse_boxes)
-        : d_(d), f_(out), err_(err), fuse_(fuse_boxes) {}
+    // own_hierarchy (f32 stream only): the stream's BOX records are not the reference's bvh_nodes but a surface-area-
+    // heuristic hierarchy built here over ALL primitives of a frame (see emit_group()).
+    Flattener(const rt_scene_desc &d, Flat<R> &out, std::string &err, bool fuse_boxes, bool own_hierarchy = false)
+        : d_(d), f_(out), err_(err), fuse_(fuse_boxes), rebuild_(own_hierarchy) {}
 
     int run() {
         int rc = validate();
@@ -75,6 +79,7 @@ template <class R> class Flattener {
             box_pad_ = 32.0 * 5.9604644775390625e-08 * 2.0 * m;
             if (const char *e = std::getenv("RT_AMD_BOX_PAD_ULPS")) box_pad_ = std::atof(e) * 5.9604644775390625e-08 * 2.0 * m; // development knob
         }
+        primary_ = primary_medium();
         f_.xforms.push_back(XformT<R>{}); // context 0 = world space
         rc = emit(d_.world_root, 0, 0);
         if (rc) return rc;
@@ -101,6 +106,9 @@ template <class R> class Flattener {
     Flat<R> &f_;
     std::string &err_;
     bool fuse_;
+    bool rebuild_;
+    int primary_ = -1; // the constant_medium that takes the fifth uniform (rt_kernels.h, Rng)
+    int cur_dup_ = 0;  // second-visit path of the span-1 bvh_nodes above the node being emitted (rt_kernels.h, Rng)
     struct Pending { // a MEDIUM_GEN record waiting for its boundary sub-stream
         int record, boundary, ctx;
     };
@@ -214,6 +222,26 @@ template <class R> class Flattener {
         }
         return RT_OK;
     }
+
+    // The constant_medium whose draw is the fifth uniform of a generator block (rt_kernels.h, Rng; the same rule as
+    // oracle/rt_oracle.cpp): the boundary box of largest surface area, the lowest node id among equals.
+    int primary_medium() const {
+        int best = -1;
+        double best_area = -1.0;
+        for (int i = 0; i < d_.n_nodes; i++) {
+            const rt_node &n = d_.nodes[i];
+            if (n.kind != RT_NODE_MEDIUM) continue;
+            const double *b = d_.nodes[n.a].bbox;
+            const double dx = b[1] - b[0], dy = b[3] - b[2], dz = b[5] - b[4];
+            const double area = 2.0 * (dx * dy + dy * dz + dz * dx);
+            if (area > best_area) {
+                best_area = area;
+                best = i;
+            }
+        }
+        return best;
+    }
+    int medium_payload(int id) const { return ((id == primary_ && cur_dup_ == 0) ? 1 : 0) | (cur_dup_ << 1); }
 
     bool contains_medium(int id, int rdepth) const {
         if (rdepth > 256) return false;
@@ -477,7 +505,14 @@ template <class R> class Flattener {
                 grow(l, h);
             }
             return RT_OK;
-        case RT_NODE_TRIANGLE: {
+        default: return baked_prim(id, x, lo, hi, true); // triangle or static sphere (bakeable() admitted nothing else)
+        }
+    }
+    // One triangle or static sphere under the rigid transform `x`: its bounds in the outer frame (padded for the rounding
+    // of the transform) and, if `do_emit`, its record.
+    int baked_prim(int id, const Rigid &x, double lo[3], double hi[3], bool do_emit) {
+        const rt_node &n = d_.nodes[id];
+        if (n.kind == RT_NODE_TRIANGLE) {
             const rt_triangle &t = d_.triangles[n.a];
             Rigid rot = x;
             rot.t[0] = rot.t[1] = rot.t[2] = 0;
@@ -488,11 +523,13 @@ template <class R> class Flattener {
             rot.apply(t.normal, nw);
             const double e1[3] = {w1[0] - w0[0], w1[1] - w0[1], w1[2] - w0[2]};
             const double e2[3] = {w2[0] - w0[0], w2[1] - w0[1], w2[2] - w0[2]};
-            const int off = push_units(3, id);
-            f_.stream[off] = UnitT<R>{{F(w0[0]), F(w0[1]), F(w0[2]), F(e1[0])}};
-            f_.stream[off + 1] = UnitT<R>{{F(e1[1]), F(e1[2]), F(e2[0]), I(make_hdr(K_TRI, 0))}};
-            f_.stream[off + 2] = UnitT<R>{{F(e2[1]), F(e2[2]), I(t.mat), I(t.cull)}};
-            f_.cold[off] = UnitT<R>{{F(nw[0]), F(nw[1]), F(nw[2]), I(id)}};
+            if (do_emit) {
+                const int off = push_units(3, id);
+                f_.stream[off] = UnitT<R>{{F(w0[0]), F(w0[1]), F(w0[2]), F(e1[0])}};
+                f_.stream[off + 1] = UnitT<R>{{F(e1[1]), F(e1[2]), F(e2[0]), I(make_hdr(K_TRI, 0))}};
+                f_.stream[off + 2] = UnitT<R>{{F(e2[1]), F(e2[2]), I(t.mat), I(t.cull)}};
+                f_.cold[off] = UnitT<R>{{F(nw[0]), F(nw[1]), F(nw[2]), I(id)}};
+            }
             for (int a = 0; a < 3; a++) {
                 const double mn = std::fmin(w0[a], std::fmin(w1[a], w2[a])), mx = std::fmax(w0[a], std::fmax(w1[a], w2[a]));
                 const double pad = 1e-6 * (std::fabs(mn) + std::fabs(mx)) + 5e-5; // aabb.h:77-80 pads thin boxes by 5e-5 too
@@ -501,21 +538,373 @@ template <class R> class Flattener {
             }
             return RT_OK;
         }
-        default: { // RT_NODE_SPHERE (bakeable() admitted nothing else)
-            const rt_sphere &sp = d_.spheres[n.a];
-            double cw[3];
-            x.apply(sp.center, cw);
+        const rt_sphere &sp = d_.spheres[n.a];
+        double cw[3];
+        x.apply(sp.center, cw);
+        if (do_emit) {
             const int off = push_units(2, id);
             f_.stream[off] = UnitT<R>{{F(cw[0]), F(cw[1]), F(cw[2]), F(sp.radius)}};
             f_.stream[off + 1] = UnitT<R>{{I(sp.mat), I(0), I(0), I(make_hdr(K_SPHERE, 0))}};
-            const double rr = std::fabs(sp.radius) * (1.0 + 1e-6) + 1e-6 * (std::fabs(cw[0]) + std::fabs(cw[1]) + std::fabs(cw[2]));
+        }
+        const double rr = std::fabs(sp.radius) * (1.0 + 1e-6) + 1e-6 * (std::fabs(cw[0]) + std::fabs(cw[1]) + std::fabs(cw[2]));
+        for (int a = 0; a < 3; a++) {
+            lo[a] = cw[a] - rr;
+            hi[a] = cw[a] + rr;
+        }
+        return RT_OK;
+    }
+
+    // ---- the float stream's own hierarchy ---------------------------------------------------------------------------
+    // world.hit() is "the closest hit over all primitives"; which boxes are tested on the way is the reference's choice
+    // (bvh.h:15-41: a RANDOM axis per node, the objects sorted along it and cut at the median; the world itself a flat list
+    // of eleven objects in final_scene), not part of the result.  The float stream therefore gets a hierarchy built for
+    // the walk the kernel does: every primitive of a frame -- whatever bvh_nodes and hittable_lists it sits under, baked
+    // instances included -- becomes a leaf, and a binned surface-area-heuristic build decides the BOX records.  An
+    // instance that cannot be baked is ONE leaf (XF_ENTER, its own hierarchy in the object frame, XF_EXIT); so is a
+    // constant_medium (its draw is keyed by its record, see rt_kernels.h Rng, so the visiting order is free).  A node
+    // whose box is nearly as large as its parent's gets no BOX record (its children stand in the parent's sequence).
+    // The double stream keeps the reference's own nodes and order: it is the parity instrument.
+    struct Leaf {
+        int id;      // description node
+        int dup;     // cur_dup_ for its emission
+        bool baked;  // triangle / static sphere emitted in the outer frame under `x`
+        Rigid x;
+        double lo[3], hi[3];
+    };
+    static void b_empty(double lo[3], double hi[3]) {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = INFINITY;
+            hi[a] = -INFINITY;
+        }
+    }
+    static void b_grow(double lo[3], double hi[3], const double l[3], const double h[3]) {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = std::fmin(lo[a], l[a]);
+            hi[a] = std::fmax(hi[a], h[a]);
+        }
+    }
+    static void b_pad_thin(double lo[3], double hi[3]) { // aabb.h:74-81: a side thinner than 0.0001 grows by half of that on either end
+        for (int a = 0; a < 3; a++)
+            if (hi[a] - lo[a] < 0.0001) {
+                lo[a] -= 0.00005;
+                hi[a] += 0.00005;
+            }
+    }
+    static double b_area(const double lo[3], const double hi[3]) {
+        const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (!(dx >= 0 && dy >= 0 && dz >= 0)) return 0.0;
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
+    }
+    // bounds of description node `id` in its own frame, from the geometry (the description's bbox fields are the caller's)
+    int geom_bounds(int id, double lo[3], double hi[3], int rdepth) {
+        if (rdepth > 256) return fail(RT_ERR_INVALID, "scene graph too deep (cycle?)");
+        const rt_node &n = d_.nodes[id];
+        b_empty(lo, hi);
+        double l[3], h[3];
+        switch (n.kind) {
+        case RT_NODE_BVH: {
+            int rc = geom_bounds(n.a, lo, hi, rdepth + 1);
+            if (rc || n.b == n.a) return rc;
+            rc = geom_bounds(n.b, l, h, rdepth + 1);
+            b_grow(lo, hi, l, h);
+            return rc;
+        }
+        case RT_NODE_LIST:
+            for (int k = 0; k < n.b; k++) {
+                int rc = geom_bounds(d_.child_index[n.a + k], l, h, rdepth + 1);
+                if (rc) return rc;
+                b_grow(lo, hi, l, h);
+            }
+            return RT_OK;
+        case RT_NODE_TRANSLATE: {
+            int rc = geom_bounds(n.a, lo, hi, rdepth + 1);
             for (int a = 0; a < 3; a++) {
-                lo[a] = cw[a] - rr;
-                hi[a] = cw[a] + rr;
+                lo[a] += n.p[a];
+                hi[a] += n.p[a];
+            }
+            return rc;
+        }
+        case RT_NODE_ROTATE_Y: { // hittable.h:86-107: the box of the eight rotated corners
+            int rc = geom_bounds(n.a, l, h, rdepth + 1);
+            if (rc) return rc;
+            if (!(l[0] <= h[0])) return RT_OK; // empty
+            const double sn = n.p[0], cs = n.p[1];
+            for (int c = 0; c < 8; c++) {
+                const double x = (c & 1) ? h[0] : l[0], y = (c & 2) ? h[1] : l[1], z = (c & 4) ? h[2] : l[2];
+                const double q[3] = {cs * x + sn * z, y, -sn * x + cs * z};
+                b_grow(lo, hi, q, q);
             }
             return RT_OK;
         }
+        case RT_NODE_MEDIUM: return geom_bounds(n.a, lo, hi, rdepth + 1);
+        case RT_NODE_SPHERE: {
+            const rt_sphere &s = d_.spheres[n.a];
+            const double r = std::fabs(s.radius);
+            for (int a = 0; a < 3; a++) { // sphere.h:14-27: the boxes at time 0 and time 1
+                const double c0 = s.center[a], c1 = s.center[a] + s.dcenter[a];
+                lo[a] = std::fmin(c0, c1) - r;
+                hi[a] = std::fmax(c0, c1) + r;
+            }
+            return RT_OK;
         }
+        case RT_NODE_QUAD: {
+            const rt_quad &q = d_.quads[n.a];
+            for (int c = 0; c < 4; c++) {
+                double v[3];
+                for (int a = 0; a < 3; a++) v[a] = q.Q[a] + ((c & 1) ? q.u[a] : 0.0) + ((c & 2) ? q.v[a] : 0.0);
+                b_grow(lo, hi, v, v);
+            }
+            b_pad_thin(lo, hi);
+            return RT_OK;
+        }
+        case RT_NODE_TRIANGLE: {
+            const rt_triangle &t = d_.triangles[n.a];
+            b_grow(lo, hi, t.v0, t.v0);
+            b_grow(lo, hi, t.v1, t.v1);
+            b_grow(lo, hi, t.v2, t.v2);
+            b_pad_thin(lo, hi);
+            return RT_OK;
+        }
+        }
+        return fail(RT_ERR_INVALID, "bad node kind");
+    }
+
+    // the leaves below description node `id` (frame of context `ctx`; `x` = accumulated rigid transform of a bakeable subtree)
+    int collect(int id, int ctx, const Rigid &x, bool in_baked, int dup, int rdepth, std::vector<Leaf> &out) {
+        if (rdepth > 256) return fail(RT_ERR_INVALID, "scene graph too deep (cycle?)");
+        if (out.size() > kMaxUnits / 2) return fail(RT_ERR_NOMEM, "flattened scene too large");
+        const rt_node &n = d_.nodes[id];
+        switch (n.kind) {
+        case RT_NODE_BVH: {
+            const bool twice = n.b == n.a && !in_baked && contains_medium(n.a, 0); // see emit(): the reference hits a span-1 child twice
+            if (twice && dup >= (1 << 14)) return fail(RT_ERR_UNSUPPORTED, "constant_medium below more than 14 nested span-1 bvh_nodes");
+            int rc = collect(n.a, ctx, x, in_baked, twice ? 2 * dup : dup, rdepth + 1, out);
+            if (rc) return rc;
+            if (n.b != n.a) return collect(n.b, ctx, x, in_baked, dup, rdepth + 1, out);
+            if (twice) return collect(n.b, ctx, x, in_baked, 2 * dup + 1, rdepth + 1, out);
+            return RT_OK;
+        }
+        case RT_NODE_LIST: {
+            double lo[3], hi[3];
+            int mat, face_id[6], outward;
+            if (!in_baked && fuse_ && match_box(id, lo, hi, mat, face_id, outward)) {
+                Leaf lf{id, dup, false, Rigid{}, {lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}};
+                out.push_back(lf);
+                return RT_OK;
+            }
+            for (int k = 0; k < n.b; k++) {
+                int rc = collect(d_.child_index[n.a + k], ctx, x, in_baked, dup, rdepth + 1, out);
+                if (rc) return rc;
+            }
+            return RT_OK;
+        }
+        case RT_NODE_TRANSLATE:
+        case RT_NODE_ROTATE_Y:
+            if (in_baked || (ctx == 0 && bakeable(id))) { // compose (see emit_baked) and look through
+                Rigid y = x;
+                if (n.kind == RT_NODE_TRANSLATE) {
+                    const double z[3] = {0, 0, 0};
+                    double r0[3], r1[3];
+                    Rigid rot = x;
+                    rot.t[0] = rot.t[1] = rot.t[2] = 0;
+                    rot.apply(n.p, r0);
+                    rot.apply(z, r1);
+                    for (int a = 0; a < 3; a++) y.t[a] = x.t[a] + (r0[a] - r1[a]);
+                } else {
+                    const double sn = n.p[0], cs = n.p[1];
+                    y.c = x.c * cs - x.s * sn;
+                    y.s = x.s * cs + x.c * sn;
+                }
+                if (!in_baked) f_.n_baked_instances++;
+                return collect(n.a, ctx, y, true, dup, rdepth + 1, out);
+            }
+            [[fallthrough]];
+        default: { // a primitive, a constant_medium or an instance that stays an instance: one leaf
+            Leaf lf{id, dup, in_baked, x, {0, 0, 0}, {0, 0, 0}};
+            int rc = in_baked ? baked_prim(id, x, lf.lo, lf.hi, false) : geom_bounds(id, lf.lo, lf.hi, rdepth);
+            if (rc) return rc;
+            if (!(lf.lo[0] <= lf.hi[0] && lf.lo[1] <= lf.hi[1] && lf.lo[2] <= lf.hi[2])) {
+                if (n.kind == RT_NODE_SPHERE || n.kind == RT_NODE_QUAD || n.kind == RT_NODE_TRIANGLE)
+                    return fail(RT_ERR_INVALID, "node " + std::to_string(id) + ": primitive with NaN coordinates");
+                return RT_OK; // an empty list behind an instance or a medium: nothing to hit
+            }
+            out.push_back(lf);
+            return RT_OK;
+        }
+        }
+    }
+
+    int emit_leaf(const Leaf &lf, int ctx, int rdepth) {
+        const int dup = cur_dup_;
+        cur_dup_ = lf.dup;
+        double lo[3], hi[3];
+        const int rc = lf.baked ? baked_prim(lf.id, lf.x, lo, hi, true) : emit(lf.id, ctx, rdepth + 1);
+        cur_dup_ = dup;
+        return rc;
+    }
+
+    // Measured on final_scene 1080p (ms / frame; the reference's own nodes and order: 850).  Children in split order 858,
+    // larger box first 814, fewer leaves first 799, larger box area PER LEAF first 792 (the side that is cheap to search
+    // and likely to be hit goes first: a hit found there culls the other side's boxes); with BOX records for all nodes
+    // below 0.8 (two leaves) / 0.95 (more) of the parent's area 763.  A node of two leaves boxed only below 0.4: 901.
+    struct BuildKnobs {
+        double thr2 = 0.8, thrn = 0.95; // a node of 2 / of more leaves gets a BOX record if its area is below this share of its parent's
+        int order = 5;                  // which child goes first: see build()
+        int bins = 16;
+        BuildKnobs() { // development knobs
+            if (const char *e = std::getenv("RT_AMD_BVH_T2")) thr2 = std::atof(e);
+            if (const char *e = std::getenv("RT_AMD_BVH_TN")) thrn = std::atof(e);
+            if (const char *e = std::getenv("RT_AMD_BVH_ORDER")) order = std::atoi(e);
+        }
+    };
+    BuildKnobs knobs_;
+
+    // idx[0 .. n): leaves of one node.  parent_area: area of the closest ancestor that has a BOX record.
+    int build(const std::vector<Leaf> &lv, int *idx, int n, int ctx, int rdepth, double parent_area, int bdepth) {
+        if (f_.stream.size() > kMaxUnits) return fail(RT_ERR_NOMEM, "flattened scene too large");
+        if (n == 1) return emit_leaf(lv[idx[0]], ctx, rdepth);
+        double lo[3], hi[3], clo[3], chi[3];
+        b_empty(lo, hi);
+        b_empty(clo, chi);
+        for (int k = 0; k < n; k++) {
+            const Leaf &l = lv[idx[k]];
+            b_grow(lo, hi, l.lo, l.hi);
+            const double c[3] = {0.5 * (l.lo[0] + l.hi[0]), 0.5 * (l.lo[1] + l.hi[1]), 0.5 * (l.lo[2] + l.hi[2])};
+            b_grow(clo, chi, c, c);
+        }
+        const double area = b_area(lo, hi);
+        const bool boxed = area < (n == 2 ? knobs_.thr2 : knobs_.thrn) * parent_area;
+        int self = -1;
+        if (boxed) {
+            self = push_units(2, -1);
+            R rl[3], rh[3];
+            for (int a = 0; a < 3; a++) {
+                const double pad = (hi[a] - lo[a]) < 2 * box_pad_ ? box_pad_ : 0.0;
+                cvt_lo(lo[a] - pad, rl[a]);
+                cvt_hi(hi[a] + pad, rh[a]);
+            }
+            f_.stream[self] = UnitT<R>{{rl[0], rh[0], rl[1], rh[1]}};
+            f_.stream[self + 1] = UnitT<R>{{rl[2], rh[2], I(0), I(make_hdr(K_BOX, 0))}};
+        }
+        // binned surface-area heuristic over the centroids: cost(split) = area(L) * |L| + area(R) * |R|
+        int n_left = -1;
+        if (n > 2 && bdepth < 64) {
+            const int NB = knobs_.bins;
+            double best = INFINITY;
+            int best_axis = -1, best_bin = -1;
+            for (int a = 0; a < 3; a++) {
+                const double ext = chi[a] - clo[a];
+                if (!(ext > 0) || !std::isfinite(ext)) continue;
+                struct Bin { double lo[3], hi[3]; int n; } bin[32];
+                for (int b = 0; b < NB; b++) { b_empty(bin[b].lo, bin[b].hi); bin[b].n = 0; }
+                const double sc = NB / ext;
+                for (int k = 0; k < n; k++) {
+                    const Leaf &l = lv[idx[k]];
+                    int b = (int)((0.5 * (l.lo[a] + l.hi[a]) - clo[a]) * sc);
+                    b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                    b_grow(bin[b].lo, bin[b].hi, l.lo, l.hi);
+                    bin[b].n++;
+                }
+                double ra[32];
+                int rn[32];
+                double l3[3], h3[3];
+                b_empty(l3, h3);
+                int cnt = 0;
+                for (int b = NB - 1; b > 0; b--) {
+                    b_grow(l3, h3, bin[b].lo, bin[b].hi);
+                    cnt += bin[b].n;
+                    ra[b] = b_area(l3, h3);
+                    rn[b] = cnt;
+                }
+                b_empty(l3, h3);
+                cnt = 0;
+                for (int b = 0; b + 1 < NB; b++) { // left = bins 0..b
+                    b_grow(l3, h3, bin[b].lo, bin[b].hi);
+                    cnt += bin[b].n;
+                    if (cnt == 0 || rn[b + 1] == 0) continue;
+                    const double cost = b_area(l3, h3) * cnt + ra[b + 1] * rn[b + 1];
+                    if (cost < best) { best = cost; best_axis = a; best_bin = b; }
+                }
+            }
+            if (best_axis >= 0) {
+                const int a = best_axis;
+                const double sc = NB / (chi[a] - clo[a]);
+                int *mid = std::partition(idx, idx + n, [&](int k) {
+                    const Leaf &l = lv[k];
+                    int b = (int)((0.5 * (l.lo[a] + l.hi[a]) - clo[a]) * sc);
+                    b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                    return b <= best_bin;
+                });
+                n_left = (int)(mid - idx);
+            }
+        }
+        if (n_left <= 0 || n_left >= n) { // no useful split (equal centroids, two leaves, depth guard): halves, along the widest centroid axis
+            int a = 0;
+            for (int k = 1; k < 3; k++)
+                if (chi[k] - clo[k] > chi[a] - clo[a]) a = k;
+            n_left = n / 2;
+            std::nth_element(idx, idx + n_left, idx + n, [&](int p, int q) {
+                const double cp = lv[p].lo[a] + lv[p].hi[a], cq = lv[q].lo[a] + lv[q].hi[a];
+                return cp < cq || (cp == cq && p < q);
+            });
+        }
+        // keep the reference's relative order inside each side (the leaves were collected in its visiting order)
+        std::sort(idx, idx + n_left);
+        std::sort(idx + n_left, idx + n);
+        // Which side goes first in the stream (the walk has no stack, so the order is the same for every ray).  0: as split
+        // (low centroids), 1 / 2: larger / smaller box, 3 / 4: more / fewer leaves, 5: larger box area per leaf, 6: larger
+        // area per tree level, 7 / 8: larger / smaller (share of the box its leaves cover) / (tree levels).
+        int first = 0;
+        if (knobs_.order != 0) {
+            double al[3], ah[3], bl[3], bh[3];
+            b_empty(al, ah);
+            b_empty(bl, bh);
+            for (int k = 0; k < n_left; k++) b_grow(al, ah, lv[idx[k]].lo, lv[idx[k]].hi);
+            for (int k = n_left; k < n; k++) b_grow(bl, bh, lv[idx[k]].lo, lv[idx[k]].hi);
+            if (knobs_.order <= 2) {
+                const bool left_larger = b_area(al, ah) >= b_area(bl, bh);
+                first = (knobs_.order == 1) == left_larger ? 0 : 1;
+            } else if (knobs_.order <= 4) {
+                const bool left_more = n_left >= n - n_left;
+                first = (knobs_.order == 3) == left_more ? 0 : 1;
+            } else if (knobs_.order == 5) { // larger area per leaf first
+                const bool l = b_area(al, ah) * (n - n_left) >= b_area(bl, bh) * n_left;
+                first = l ? 0 : 1;
+            } else if (knobs_.order >= 7) { // the side more likely to end the search, per unit of work, first
+                double sl = 0, sr = 0;
+                for (int k = 0; k < n_left; k++) sl += b_area(lv[idx[k]].lo, lv[idx[k]].hi);
+                for (int k = n_left; k < n; k++) sr += b_area(lv[idx[k]].lo, lv[idx[k]].hi);
+                const double fl = std::fmin(1.0, sl / std::fmax(b_area(al, ah), 1e-300)), fr = std::fmin(1.0, sr / std::fmax(b_area(bl, bh), 1e-300));
+                const double cl = 1.0 + std::log2((double)n_left), cr = 1.0 + std::log2((double)(n - n_left));
+                first = (fl * cr >= fr * cl) == (knobs_.order == 7) ? 0 : 1;
+            } else { // 6: larger area per level of its subtree first
+                const double cl = 1.0 + std::log2((double)n_left), cr = 1.0 + std::log2((double)(n - n_left));
+                first = b_area(al, ah) * cr >= b_area(bl, bh) * cl ? 0 : 1;
+            }
+        }
+        const double pa = boxed ? area : parent_area;
+        for (int side = 0; side < 2; side++) {
+            const bool left = (side == 0) == (first == 0);
+            int rc = left ? build(lv, idx, n_left, ctx, rdepth, pa, bdepth + 1) : build(lv, idx + n_left, n - n_left, ctx, rdepth, pa, bdepth + 1);
+            if (rc) return rc;
+        }
+        if (boxed) f_.stream[self + 1].w[2] = I(pos());
+        return RT_OK;
+    }
+
+    // everything below description node `id` (a bvh_node, a hittable_list or a bakeable instance), under a hierarchy of our own
+    int emit_group(int id, int ctx, int rdepth) {
+        std::vector<Leaf> lv;
+        int rc = collect(id, ctx, Rigid{}, false, cur_dup_, rdepth, lv);
+        if (rc || lv.empty()) return rc;
+        std::vector<int> idx(lv.size());
+        std::iota(idx.begin(), idx.end(), 0);
+        // the world's own box is hit by nearly every ray (final_scene: the fog's boundary is in it): no BOX record for it
+        const bool top = id == d_.world_root && ctx == 0;
+        double lo[3], hi[3];
+        b_empty(lo, hi);
+        for (const Leaf &l : lv) b_grow(lo, hi, l.lo, l.hi);
+        return build(lv, idx.data(), (int)lv.size(), ctx, rdepth, top ? b_area(lo, hi) : INFINITY, 0);
     }
 
     // Emit the subtree of description node `id` in the reference's visiting order.
@@ -525,6 +914,7 @@ template <class R> class Flattener {
         const rt_node &n = d_.nodes[id];
         switch (n.kind) {
         case RT_NODE_BVH: { // bvh.h:43-51: own box, then left, then right
+            if (rebuild_) return emit_group(id, ctx, rdepth);
             const int self = push_units(2, id);
             R lo[3], hi[3];
             for (int a = 0; a < 3; a++) {
@@ -534,15 +924,22 @@ template <class R> class Flattener {
             }
             f_.stream[self] = UnitT<R>{{lo[0], hi[0], lo[1], hi[1]}};
             f_.stream[self + 1] = UnitT<R>{{lo[2], hi[2], I(0), I(make_hdr(K_BOX, 0))}};
-            int rc = emit(n.a, ctx, rdepth + 1);
-            if (rc) return rc;
             // span-1 nodes have left == right (bvh.h:30) and the reference visits the child twice.  For geometry the second
             // visit cannot change the result; a constant_medium draws a NEW uniform on it (constant_medium.h:41), i.e. the
-            // reference scatters in such a medium at the closer of two free paths -- so that child is emitted twice.
-            if (n.b != n.a || contains_medium(n.a, 0)) {
+            // reference scatters in such a medium at the closer of two free paths -- so that child is emitted twice, the
+            // copies told apart by cur_dup_ (which keys their draws).
+            const bool twice = n.b == n.a && contains_medium(n.a, 0);
+            const int dup = cur_dup_;
+            if (twice && dup >= (1 << 14)) return fail(RT_ERR_UNSUPPORTED, "constant_medium below more than 14 nested span-1 bvh_nodes");
+            if (twice) cur_dup_ = 2 * dup;
+            int rc = emit(n.a, ctx, rdepth + 1);
+            if (rc) return rc;
+            if (n.b != n.a || twice) {
+                if (twice) cur_dup_ = 2 * dup + 1;
                 rc = emit(n.b, ctx, rdepth + 1);
                 if (rc) return rc;
             }
+            cur_dup_ = dup;
             f_.stream[self + 1].w[2] = I(pos());
             return RT_OK;
         }
@@ -558,6 +955,7 @@ template <class R> class Flattener {
                 f_.n_fused_boxes++;
                 return RT_OK;
             }
+            if (rebuild_) return emit_group(id, ctx, rdepth);
             for (int k = 0; k < n.b; k++) {
                 int rc = emit(d_.child_index[n.a + k], ctx, rdepth + 1);
                 if (rc) return rc;
@@ -566,6 +964,7 @@ template <class R> class Flattener {
         }
         case RT_NODE_TRANSLATE:
         case RT_NODE_ROTATE_Y: {
+            if (rebuild_ && ctx == 0 && bakeable(id)) return emit_group(id, ctx, rdepth);
             if (fuse_ && ctx == 0 && bakeable(id)) {
                 double lo[3], hi[3];
                 f_.n_baked_instances++;
@@ -607,14 +1006,14 @@ template <class R> class Flattener {
                 if (contains_medium(n.a, 0)) return fail(RT_ERR_UNSUPPORTED, "constant_medium inside the boundary of a constant_medium");
                 const int off = push_units(2, id);
                 f_.stream[off] = UnitT<R>{{I(0), R(0), R(0), R(0)}};
-                f_.stream[off + 1] = UnitT<R>{{F(n.p[0]), I(n.b), I(id), I(make_hdr(K_MEDIUM_GEN, 0))}};
+                f_.stream[off + 1] = UnitT<R>{{F(n.p[0]), I(n.b), I(id), I(make_hdr(K_MEDIUM_GEN, medium_payload(id)))}};
                 pending_.push_back(Pending{off, n.a, ctx});
                 return RT_OK;
             }
             const rt_sphere &s = d_.spheres[b.a];
             const int off = push_units(2, id);
             f_.stream[off] = UnitT<R>{{F(s.center[0]), F(s.center[1]), F(s.center[2]), F(s.radius)}};
-            f_.stream[off + 1] = UnitT<R>{{F(n.p[0]), I(n.b), I(id), I(make_hdr(K_MEDIUM, 0))}};
+            f_.stream[off + 1] = UnitT<R>{{F(n.p[0]), I(n.b), I(id), I(make_hdr(K_MEDIUM, medium_payload(id)))}};
             return RT_OK;
         }
         case RT_NODE_SPHERE: {

@@ -159,11 +159,14 @@ template <> RT_DEV float u01<float>(uint32_t x) { return (x >> 8) * (1.0f / 1677
 
 // Stream protocol (shared with oracle/rt_oracle.cpp): counter = (block, sample, pixel, stream); stream 0 = the camera
 // ray's draws (get_ray), 0x80000000|b = the draws of ray_color invocation b of the path (scatter + mixture pdf),
-// 1+b = constant_medium draws keyed by node id -- except the FIRST medium that draws while ray b is traced: it takes the
-// fifth uniform (fifth()) of the block that started the ray's predecessor (camera block for ray 0, bounce b-1's block 0
-// otherwise), which the lane carries in `med_xi` (< 0 once used): final_scene's fog draws on every ray, and a generator
-// call per ray for it was 3 % of the frame.  begin*() computes block 0 unconditionally -- a wave-uniform point, so the
-// common case (<= 4 draws per bounce) never runs the generator under a divergent branch.
+// 1+b (+ dup << 16) = constant_medium draws keyed by node id -- except the scene's PRIMARY medium (the one with the
+// largest boundary box, chosen at upload: final_scene's fog, which draws on every ray -- a generator call per ray for it
+// was 3 % of the frame): it takes the fifth uniform (fifth()) of the block that started the ray's predecessor (camera
+// block for ray 0, bounce b-1's block 0 otherwise), which the lane carries in `med_xi`.  Which uniform a medium gets is
+// fixed by its record (header payload: bit 0 = takes the fifth uniform, bits 1.. = dup, the second-visit path of span-1
+// bvh_nodes above it), not by the order in which the ray meets the scene's media: the float stream's hierarchy is not
+// the reference's.  begin*() computes block 0 unconditionally -- a wave-uniform point, so the common case (<= 4 draws
+// per bounce) never runs the generator under a divergent branch.
 template <class R> struct Rng {
     uint32_t k0, k1, pixel, sample, stream, block;
     uint32_t b0, b1, b2, b3;
@@ -189,9 +192,9 @@ template <class R> struct Rng {
     RT_DEV R next(R mn, R mx) { return mn + (mx - mn) * next(); } // utils.h:38
 };
 // keyed draw for constant_medium.h:41
-template <class R> RT_DEV R medium_draw(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, int node_id, int bounce) {
+template <class R> RT_DEV R medium_draw(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, int node_id, int bounce, int dup) {
     uint32_t o0, o1, o2, o3;
-    philox4x32((uint32_t)node_id, sample, pixel, 1u + (uint32_t)bounce, k0, k1, o0, o1, o2, o3);
+    philox4x32((uint32_t)node_id, sample, pixel, 1u + (uint32_t)bounce + ((uint32_t)dup << 16), k0, k1, o0, o1, o2, o3);
     return u01<R>(o0);
 }
 
@@ -449,14 +452,14 @@ RT_DEV bool tri_t(V3<R> v0, V3<R> edge1, V3<R> edge2, int cull, V3<R> ro, V3<R> 
 // constant_medium.h:30-44: the boundary is entered at t1 and left at t2 (both hits found); clip to the ray's interval, draw
 // the free path.  The uniform is drawn only where the reference draws it (line 41).
 template <class R, class XiFn>
-RT_DEV bool medium_span(R t1, R t2, R neg_inv_density, int node_id, V3<R> rd, R tmin, R tmax, XiFn xi_fn, R &t_out) {
+RT_DEV bool medium_span(R t1, R t2, R neg_inv_density, int node_id, int sel, V3<R> rd, R tmin, R tmax, XiFn xi_fn, R &t_out) {
     if (t1 < tmin) t1 = tmin;
     if (t2 > tmax) t2 = tmax;
     if (t1 >= t2) return false;
     if (t1 < R(0)) t1 = R(0);
     R ray_length = len(rd);
     R distance_inside_boundary = (t2 - t1) * ray_length;
-    R hit_distance = neg_inv_density * m_log(xi_fn(node_id));
+    R hit_distance = neg_inv_density * m_log(xi_fn(node_id, sel)); // sel = the record's header payload (see Rng)
     if (hit_distance > distance_inside_boundary) return false;
     t_out = t1 + m_div(hit_distance, ray_length);
     return true;
@@ -464,8 +467,8 @@ RT_DEV bool medium_span(R t1, R t2, R neg_inv_density, int node_id, V3<R> rd, R 
 
 // constant_medium.h:21 (boundary is a static sphere)
 template <class R, class XiFn>
-RT_DEV bool medium_t(V3<R> cc, R radius, R neg_inv_density, int node_id, V3<R> ro, V3<R> rd, R tmin, R tmax, XiFn xi_fn,
-                     R &t_out) {
+RT_DEV bool medium_t(V3<R> cc, R radius, R neg_inv_density, int node_id, int sel, V3<R> ro, V3<R> rd, R tmin, R tmax,
+                     XiFn xi_fn, R &t_out) {
     R t1, t2;
     if constexpr (sizeof(R) == 4) {
         // both boundary hits from ONE solve of the quadratic (same conditioned form as sphere_t): over the whole line the
@@ -487,7 +490,7 @@ RT_DEV bool medium_t(V3<R> cc, R radius, R neg_inv_density, int node_id, V3<R> r
         if (!sphere_t(cc, radius, ro, rd, -Const<R>::inf, Const<R>::inf, t1)) return false;
         if (!sphere_t(cc, radius, ro, rd, t1 + R(0.0001), Const<R>::inf, t2)) return false;
     }
-    return medium_span(t1, t2, neg_inv_density, node_id, rd, tmin, tmax, xi_fn, t_out);
+    return medium_span(t1, t2, neg_inv_density, node_id, sel, rd, tmin, tmax, xi_fn, t_out);
 }
 
 template <class R> RT_DEV void xf_apply(int kind, R p0, R p1, R p2, V3<R> &o, V3<R> &d) {
@@ -614,8 +617,8 @@ RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SC &sc, Trav<R> &tv
         next = i + 3 * U;
     } else if (kind == K_MEDIUM) {
         R t;
-        if (medium_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], tv.u1.w[0], ldi(tv.u1.w[2]), tv.o, tv.d, tmin,
-                     tv.best_t, medium_xi, t)) {
+        if (medium_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], tv.u1.w[0], ldi(tv.u1.w[2]), tv.hdr >> 4, tv.o, tv.d,
+                     tmin, tv.best_t, medium_xi, t)) {
             tv.best_t = t; tv.best_off = i; tv.best_ctx = tv.ctx;
         }
     } else if (GM && kind == K_MEDIUM_GEN) {
@@ -639,7 +642,7 @@ RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SC &sc, Trav<R> &tv
             };
             R t1, t2, t;
             if (boundary_hit(-Const<R>::inf, t1) && boundary_hit(t1 + R(0.0001), t2) &&
-                medium_span(t1, t2, tv.u1.w[0], ldi(tv.u1.w[2]), tv.d, tmin, tv.best_t, medium_xi, t)) {
+                medium_span(t1, t2, tv.u1.w[0], ldi(tv.u1.w[2]), tv.hdr >> 4, tv.d, tmin, tv.best_t, medium_xi, t)) {
                 tv.best_t = t; tv.best_off = i; tv.best_ctx = tv.ctx;
             }
         }
@@ -1255,7 +1258,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     Trav<R> tv;
     tv.i = 0;
     tv.hdr = K_IDLE;
-    R med_xi = R(-1);   // the uniform for the first constant_medium that draws on this ray (< 0: used)
+    R med_xi = R(0);    // the uniform of the scene's primary constant_medium on this ray (see Rng)
     int bounce = 0;     // index of the ray this lane traces within its path (0 = camera ray)
     int smp = 0;        // the unit this lane works on: sample index,
     int pp = 0;         //   pixel within the tile | accumulator slot << 6,
@@ -1356,15 +1359,14 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             }
             if (leaf_trip && mm != 0ull) {
                 if (is_med) {
-                    auto mxi = [&](int node_id) {
+                    auto mxi = [&](int node_id, int sel) {
                         R x = med_xi;
-                        if (x < R(0)) x = medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce);
-                        med_xi = R(-1);
+                        if (sel != 1) x = medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce, sel >> 1);
                         return x;
                     };
                     R t;
-                    if (medium_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], tv.u1.w[0], ldi(tv.u1.w[2]), tv.o, tv.d, tmin,
-                                 tv.best_t, mxi, t)) {
+                    if (medium_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], tv.u1.w[0], ldi(tv.u1.w[2]), tv.hdr >> 4, tv.o, tv.d,
+                                 tmin, tv.best_t, mxi, t)) {
                         tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx;
                     }
                     trav_goto(mem, tv, tv.i + 2 * Pos<R>::unit);
@@ -1372,10 +1374,9 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             }
             if (leaf_trip && mo != 0ull) {
                 if (is_oth) {
-                    auto mxi = [&](int node_id) {
+                    auto mxi = [&](int node_id, int sel) {
                         R x = med_xi;
-                        if (x < R(0)) x = medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce);
-                        med_xi = R(-1);
+                        if (sel != 1) x = medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce, sel >> 1);
                         return x;
                     };
                     trav_leaf_step<GEN_MEDIUM>(mem, sc, tv, ray, tmin, mxi);
@@ -1593,10 +1594,10 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(SceneT<R> sc_arg, const rt
         r.d = mk<R>(R(rays[k].dir[0]), R(rays[k].dir[1]), R(rays[k].dir[2]));
         r.tm = R(rays[k].time);
         const R xik = a.has_xi ? R(xi[k]) : R(0);
-        auto mxi = [&](int node_id) {
+        auto mxi = [&](int node_id, int sel) {
             if (a.has_xi) return xik;
             uint32_t o0, o1, o2, o3;
-            philox4x32((uint32_t)node_id, (uint32_t)k, (uint32_t)((uint64_t)k >> 32), 0x7fffffffu, a.k0, a.k1, o0, o1, o2, o3);
+            philox4x32((uint32_t)node_id, (uint32_t)k, (uint32_t)((uint64_t)k >> 32), 0x7fffffffu - (uint32_t)(sel >> 1), a.k0, a.k1, o0, o1, o2, o3);
             return u01<R>(o0);
         };
         Trav<R> tv;

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")  # RT_AMD_LIB: diagnostic builds
 
 EXPORTS = ["rt_abi_sizeof", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_upload", "rt_scene_free",
-           "rt_scene_info", "rt_scene_flatten_info", "rt_trace_batch", "rt_render_device", "rt_tonemap_device", "rt_render",
+           "rt_scene_info", "rt_scene_flatten_info", "rt_scene_flatten_stream", "rt_trace_batch", "rt_render_device", "rt_tonemap_device", "rt_render",
            "rt_render_multi", "rt_render_static"]
 
 _lib = None
@@ -60,6 +60,8 @@ def load() -> C.CDLL:
     L.rt_scene_info.argtypes = [vp, vp]
     L.rt_scene_flatten_info.restype = C.c_int
     L.rt_scene_flatten_info.argtypes = [C.POINTER(abi.SceneDesc), vp]
+    L.rt_scene_flatten_stream.restype = C.c_int
+    L.rt_scene_flatten_stream.argtypes = [C.POINTER(abi.SceneDesc), vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.rt_trace_batch.restype = C.c_int
     L.rt_trace_batch.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, C.c_int]
     L.rt_render_device.restype = C.c_int
@@ -87,6 +89,23 @@ def flatten_info(scene: abi.Scene) -> dict:
         raise RtError(f"rt_scene_flatten_info failed with status {rc}")
     return {"f32_units": int(out[0]), "f64_units": int(out[1]), "fused_boxes": int(out[2]), "lights": int(out[3]),
             "baked_instances": int(out[4])}
+
+
+def flatten_stream(scene: abi.Scene):
+    """Host-only: the f32 record stream rt_scene_upload would build, as (units, node_ids): a (n, 4) uint32 array of
+    16-byte units (layout: csrc/rt_scene.h) and the description node id of the record starting at each unit (-1: none)."""
+    L = load()
+    d = scene.desc()
+    n = C.c_size_t(0)
+    rc = L.rt_scene_flatten_stream(C.byref(d), None, None, 0, C.byref(n))
+    if rc != abi.RT_OK:
+        raise RtError(f"rt_scene_flatten_stream failed with status {rc}")
+    units = np.zeros((n.value, 4), dtype=np.uint32)
+    ids = np.zeros(n.value, dtype=np.int32)
+    rc = L.rt_scene_flatten_stream(C.byref(d), units.ctypes.data, ids.ctypes.data, n.value, C.byref(n))
+    if rc != abi.RT_OK:
+        raise RtError(f"rt_scene_flatten_stream failed with status {rc}")
+    return units, ids
 
 
 class Context:

@@ -210,6 +210,20 @@ def _cos_theta(ray, hit):
     return max(c, 1e-3)
 
 
+def _same_surface(sc, a, b):
+    na, nb = sc.nodes[a], sc.nodes[b]
+    if int(na["kind"]) != abi.RT_NODE_QUAD or int(nb["kind"]) != abi.RT_NODE_QUAD:
+        return False
+    qa, qb = sc.quads[int(na["a"])], sc.quads[int(nb["a"])]
+    if int(qa["mat"]) != int(qb["mat"]):
+        return False
+    n1, n2 = np.array(qa["normal"]), np.array(qb["normal"])
+    c = float(n1 @ n2)
+    if abs(abs(c) - 1.0) > 1e-12:
+        return False
+    return abs(float(qa["D"]) - math.copysign(1.0, c) * float(qb["D"])) <= 1e-9 * max(1.0, abs(float(qa["D"])))
+
+
 def classify(sc: abi.Scene, rays, ref, got, xi=None):
     """One row per ray that is not a plain both-miss: dict with index, status ('same' | 'tie' | 'grazing' | 'unexplained'),
     the measured errors and the bounds."""
@@ -261,6 +275,15 @@ def classify(sc: abi.Scene, rays, ref, got, xi=None):
         status, why = "unexplained", ""
         if r >= 0 and g >= 0 and abs(t_g - t_r) <= max(BAR * abs(t_r), slack_t):
             status, why = "tie", f"|dt| = {abs(t_g - t_r):.3g} <= {max(BAR * abs(t_r), slack_t):.3g}"
+            if _same_surface(sc, r, g) and float(np.abs(np.array(got["normal"][k]) - np.array(ref["normal"][k])).max()) <= 16 * EPS32:
+                # coplanar faces of one material (final_scene's ground boxes stand wall to wall, the stored normals of two
+                # neighbours opposed): whichever of the two is named, the material gets the same point and the same
+                # (ray-facing) normal; front_face differs, which only dielectric and diffuse_light read (material.h:88,
+                # 129).  Which face the reference names is its visiting order; the float stream has a hierarchy of its own.
+                mk = int(sc.arrays["materials"]["kind"][int(sc.quads[int(nodes[r]["a"])]["mat"])])
+                if bool(got["front_face"][k] == ref["front_face"][k]) or mk in (abi.RT_MAT_LAMBERTIAN, abi.RT_MAT_METAL, abi.RT_MAT_ISOTROPIC):
+                    row["same_surface"] = True
+                    why += "; coplanar faces of one material: the same input to the material"
         else:
             # the hit one side has and the other lacks: how robustly does the double path accept / reject it?
             if t_g > t_r:   # float lost the reference's primitive
@@ -291,6 +314,7 @@ def summarise(rows):
     mism = [r for r in rows if r["status"] != "same"]
     return dict(
         n_rays=len(rows), n_same=len(same), n_tie=sum(r["status"] == "tie" for r in mism),
+        n_same_surface=sum(bool(r.get("same_surface")) for r in mism),
         n_grazing=sum(r["status"] == "grazing" for r in mism), n_unexplained_id=sum(r["status"] == "unexplained" for r in mism),
         n_t_over=sum(r["rel_t"] > BAR for r in same), n_n_over=sum(r["dn"] > BAR for r in same),
         max_rel_t=max((r["rel_t"] for r in solid), default=0.0), max_dn=max((r["dn"] for r in solid), default=0.0),

@@ -94,7 +94,7 @@ def test_split_range_properties():
     assert sorted(sum((distributed.frame_shards(124, 8, r) for r in range(8)), [])) == list(range(124))
 
 
-def test_flattener_stream_sizes_and_box_fusion():
+def test_flattener_stream_sizes_and_box_fusion(monkeypatch):
     """Host-only run of the flattener (rt_scene_flatten_info): the f32 stream fuses every box() list of six axis-aligned
     quads (quad.h:103) into one AABOX record, the f64 parity stream keeps the reference's quads; malformed graphs are
     refused with a status instead of a crash."""
@@ -104,11 +104,15 @@ def test_flattener_stream_sizes_and_box_fusion():
     assert info[2]["fused_boxes"] == 1  # cornell's rotated box is axis-aligned in its own (object) space
     for n in (1, 2, 3, 4):
         assert info[n]["f32_units"] <= info[n]["f64_units"]
-    # six 5-unit quads -> one 2-unit record; the translate(rotate_y(1000 spheres)) instance (cpuRenderer.cpp:369-375) is
-    # emitted in world space in the f32 stream: no XF_ENTER / XF_EXIT pair for either transform
-    assert info[3]["f64_units"] - info[3]["f32_units"] == 400 * (6 * 5 - 2) + 4 * 2
     assert [info[n]["baked_instances"] for n in (1, 2, 3, 4)] == [0, 0, 1, 1]  # cornell's instance is a box of quads (kept: one AABOX in its own frame); mesh: the bunny
-    assert info[1]["f32_units"] == info[1]["f64_units"]
+    # with the reference's own nodes and order (development knob) the two streams differ by exactly the fused and baked
+    # records: six 5-unit quads -> one 2-unit record; the translate(rotate_y(1000 spheres)) instance (cpuRenderer.cpp:369-375)
+    # is emitted in world space in the f32 stream: no XF_ENTER / XF_EXIT pair for either transform
+    monkeypatch.setenv("RT_AMD_REF_ORDER", "1")
+    ref = {n: lib.flatten_info(fx.scene(n)) for n in (1, 3)}
+    monkeypatch.delenv("RT_AMD_REF_ORDER")
+    assert ref[3]["f64_units"] - ref[3]["f32_units"] == 400 * (6 * 5 - 2) + 4 * 2
+    assert ref[1]["f32_units"] == ref[1]["f64_units"]
     assert [info[n]["lights"] for n in (1, 2, 3, 4)] == [1, 2, 1, 2]
     # a box with one face moved is not fused
     sc = fx.scene(2)
@@ -142,3 +146,63 @@ def test_flattener_refuses_cyclic_graphs():
     dag = fx.scene(2)
     dag.nodes["b"][bvh[-1]] = dag.nodes["a"][bvh[-1]]  # the same child twice: legal (bvh.h:30 does it for span 1)
     lib.flatten_info(dag)
+
+
+_UNITS = {0: 2, 1: 2, 2: 2, 3: 2, 4: 5, 5: 3, 6: 2, 7: 2, 8: 3, 9: 2, 15: 2}  # units per record kind (csrc/rt_scene.h)
+
+
+def _records(units):
+    """[(unit offset, kind)] of every record of a stream, walked linearly (sub-streams behind the main sentinel included)."""
+    ui = units.view(np.int32)
+    out, i = [], 0
+    while i < len(units):
+        kind = int(ui[i + 1, 3]) & 15
+        assert kind in _UNITS, (i, kind)
+        out.append((i, kind))
+        i += _UNITS[kind]
+    assert i == len(units)
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 6])
+def test_own_hierarchy_holds_the_reference_leaves(monkeypatch, n):
+    """The f32 stream's BOX records are a hierarchy of the flattener's own (surface-area heuristic over all primitives of a
+    frame), not the reference's bvh_nodes.  Host-only structure check: the same leaf records as the stream in the
+    reference's order (every primitive once; a medium below a span-1 bvh_node twice), every skip link forward, on a record
+    boundary and nested within the enclosing BOX's, and every BOX inside the BOX that encloses it."""
+    sc = fx.scene(n)
+    units, ids = lib.flatten_stream(sc)
+    monkeypatch.setenv("RT_AMD_REF_ORDER", "1")
+    r_units, r_ids = lib.flatten_stream(sc)
+    monkeypatch.delenv("RT_AMD_REF_ORDER")
+    recs, r_recs = _records(units), _records(r_units)
+    leaves = sorted((int(ids[i]), k) for i, k in recs if k not in (0, 15, 6, 7))
+    r_leaves = sorted((int(r_ids[i]), k) for i, k in r_recs if k not in (0, 15, 6, 7))
+    assert leaves == r_leaves and len(leaves) > 0
+    assert sum(k == 6 for _, k in recs) == sum(k == 7 for _, k in recs)  # XF_ENTER / XF_EXIT pairs
+    starts = {i for i, _ in recs}
+    uf, ui = units.view(np.float32), units.view(np.int32)
+    open_boxes = []  # (end unit, bounds)
+    n_box = 0
+    for i, k in recs:
+        while open_boxes and open_boxes[-1][0] <= i:
+            open_boxes.pop()
+        if k == 15:
+            assert not open_boxes, "a sentinel inside a BOX's span"
+        if k in (6, 7):
+            open_boxes = [(e, None) for e, _ in open_boxes]  # bounds below an instance are in another frame
+        if k != 0:
+            continue
+        n_box += 1
+        link = int(ui[i + 1, 2])
+        assert link % 16 == 0 and link // 16 > i + 2 and link // 16 in starts, (i, link)
+        b = np.array([uf[i, 0], uf[i, 1], uf[i, 2], uf[i, 3], uf[i + 1, 0], uf[i + 1, 1]])
+        assert (b[0::2] <= b[1::2]).all()
+        if open_boxes:
+            end, outer = open_boxes[-1]
+            assert link // 16 <= end
+            if outer is not None:
+                assert (b[0::2] >= outer[0::2]).all() and (b[1::2] <= outer[1::2]).all(), (i, b, outer)
+        open_boxes.append((link // 16, b))
+    r_box = sum(k == 0 for _, k in r_recs)
+    assert n_box <= r_box + 2, "the reference puts a node above every one or two leaves; ours has no reason to need more"

@@ -48,7 +48,8 @@ def _check_f32_batch(name, sc, rays, xi, hits, got, min_same=0.99):
     unexplained = [r for r in rows if r["status"] == "unexplained"]
     assert not unexplained, f"{len(unexplained)} unexplained primitive-id mismatches, e.g. {unexplained[:3]}"
     same = [r for r in rows if r["status"] == "same"]
-    assert len(same) >= min_same * len(rows)
+    # (ties between coplanar faces of one material -- neighbouring ground boxes -- name either face: the same hit record)
+    assert len(same) + sum(bool(r.get("same_surface")) for r in rows) >= min_same * len(rows)
     for r in same:
         assert r["rel_t"] <= max(fb.BAR, r["bound_t"]), r
         assert r["dn"] <= max(fb.BAR, r["bound_n"]), r

@@ -22,3 +22,5 @@ for spec in sys.argv[1:]:
         env[k] = v
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=90)
     print(spec, "->", r.stdout.strip() or r.stderr.strip()[-300:], flush=True)
+    if r.stdout.strip() and "PROFILE" in spec:  # diagnostic builds print their tables on stderr
+        print(r.stderr.strip()[-6000:], flush=True)

@@ -29,7 +29,7 @@ for n in (1, 2, 3, 4, 6, "box3"):
     rows = fb.classify(sc, rays, hits, got, xi)
     rep = fb.summarise(rows)
     report[str(n)] = rep
-    print(f"scene {n}: {rep['n_rays']} rays, {rep['n_same']} same id, {rep['n_tie']} equal-t ties, {rep['n_grazing']} grazing, "
+    print(f"scene {n}: {rep['n_rays']} rays, {rep['n_same']} same id, {rep['n_tie']} equal-t ties ({rep['n_same_surface']} of them coplanar faces of one material), {rep['n_grazing']} grazing, "
           f"{rep['n_unexplained_id']} unexplained ids; over 1e-5: t {rep['n_t_over']} (max {rep['max_rel_t']:.3g}, max/bound {rep['max_t_over_bound']:.3g}), "
           f"normal {rep['n_n_over']} (max {rep['max_dn']:.3g}, max/bound {rep['max_n_over_bound']:.3g})")
     for r in rep["exceptions"][:14]:
@@ -40,7 +40,7 @@ json.dump(report, open("gpurun_out/f32_parity.json", "w"), indent=1)
 table = {}
 for name, rep in report.items():
     table[name] = {
-        "n_rays": rep["n_rays"], "n_same_id": rep["n_same"], "max_rel_t": rep["max_rel_t"], "max_dn": rep["max_dn"],
+        "n_rays": rep["n_rays"], "n_same_id": rep["n_same"], "n_tie_same_surface": rep["n_same_surface"], "max_rel_t": rep["max_rel_t"], "max_dn": rep["max_dn"],
         "beyond_1e-5": [{k: e[k] for k in ("index", "prim", "kind", "rel_t", "dn", "bound_t", "bound_n", "cos", "M", "dist")}
                         for e in rep["exceptions"]],
         "id_mismatches": [{k: m[k] for k in ("index", "prim", "got", "t_ref", "t_got", "status", "why")} for m in rep["mismatches"]],
