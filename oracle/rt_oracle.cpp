@@ -144,16 +144,38 @@ struct Ctx {
     void begin_sample(uint32_t px, uint32_t s) { pixel = px; sample = s; block = 0; have = 0; stream = 0; }
     void begin_bounce(int b) { block = 0; have = 0; stream = 0x80000000u | (uint32_t)b; }
 
-    double next() { // utils.h:33 random_double()
-        if (mode == RNG_GLIBC) return std::rand() / (RAND_MAX + 1.0);
-        if (mode == RNG_INJECT) return inject;
+    // The rejection loops (vec3.h:106 random_in_unit_disk, vec3.h:114 random_unit_vector) draw their candidates from a
+    // xorshift32 sub-sequence seeded by ONE word of the stream (a zero word seeds 0x9e3779b9): however many candidates a
+    // loop rejects, it costs the path one word, so that no lane of a wave sends the others through another generator
+    // block (19 % of final_scene's rays needed one: fog and metal scattering).
+    uint32_t sub = 0;
+    bool in_sub = false;
+    void sub_begin() {
+        if (mode != RNG_PHILOX) return; // std::rand / injected draws stay the reference's plain sequence
+        sub = next_word();
+        if (sub == 0) sub = 0x9e3779b9u;
+        in_sub = true;
+    }
+    void sub_end() { in_sub = false; }
+    uint32_t next_word() {
         if (have == 0) {
             philox_stream(block++, sample, pixel, stream, k0, k1, buf);
             have = 4;
         }
         uint32_t x = buf[4 - have];
         have--;
-        return x * (1.0 / 4294967296.0);
+        return x;
+    }
+    double next() { // utils.h:33 random_double()
+        if (mode == RNG_GLIBC) return std::rand() / (RAND_MAX + 1.0);
+        if (mode == RNG_INJECT) return inject;
+        if (in_sub) {
+            sub ^= sub << 13;
+            sub ^= sub >> 17;
+            sub ^= sub << 5;
+            return sub * (1.0 / 4294967296.0);
+        }
+        return next_word() * (1.0 / 4294967296.0);
     }
     double medium_draw(int node_id) { // constant_medium.h:41's random_double()
         if (mode == RNG_GLIBC) return std::rand() / (RAND_MAX + 1.0);
@@ -182,6 +204,7 @@ struct Ctx {
 #endif
 
 inline V random_in_unit_disk(Ctx &c) {
+    struct Sub { Ctx &c; Sub(Ctx &c_) : c(c_) { c.sub_begin(); } ~Sub() { c.sub_end(); } } sub(c);
     while (true) {
 #if ORC_ARGS_RIGHT_TO_LEFT
         double y = c.next(-1, 1);
@@ -207,6 +230,7 @@ inline V random_vec(Ctx &c, double mn, double mx) { // vec3.h:55
     return mk(x, y, z);
 }
 inline V random_unit_vector(Ctx &c) { // vec3.h:114
+    struct Sub { Ctx &c; Sub(Ctx &c_) : c(c_) { c.sub_begin(); } ~Sub() { c.sub_end(); } } sub(c);
     while (true) {
         V p = random_vec(c, -1, 1);
         double lensq = length_squared(p);

@@ -182,12 +182,25 @@ template <class R> struct Rng {
     RT_DEV void begin_bounce(uint32_t px, uint32_t s, int bounce) {
         pixel = px; sample = s; stream = 0x80000000u | (uint32_t)bounce; block = 0; refill();
     }
-    RT_DEV R next() { // utils.h:33 random_double()
+    RT_DEV uint32_t next_word() {
         if (have == 0) refill();
         uint32_t x = b0;
         b0 = b1; b1 = b2; b2 = b3;
         have--;
-        return u01<R>(x);
+        return x;
+    }
+    RT_DEV R next() { return u01<R>(next_word()); } // utils.h:33 random_double()
+    // Rejection loops draw their candidates from a xorshift32 sub-sequence seeded by one word of the stream (see
+    // oracle/rt_oracle.cpp Ctx::sub_begin): a loop never needs a second generator block, whatever it rejects.
+    RT_DEV uint32_t sub_begin() {
+        uint32_t s = next_word();
+        return s == 0u ? 0x9e3779b9u : s;
+    }
+    static RT_DEV R sub_next(uint32_t &s, R mn, R mx) {
+        s ^= s << 13;
+        s ^= s >> 17;
+        s ^= s << 5;
+        return mn + (mx - mn) * u01<R>(s);
     }
     RT_DEV R next(R mn, R mx) { return mn + (mx - mn) * next(); } // utils.h:38
 };
@@ -890,20 +903,22 @@ template <class R> struct Onb { // onb.h:5
 // Draw orders below follow oracle/rt_oracle.cpp (which is pinned to the compiled reference): vec3::random(-1,1)
 // consumes z, y, x; random_in_unit_disk y, x; quad::random v then u.
 template <class R> RT_DEV V3<R> random_unit_vector(Rng<R> &g) { // vec3.h:114
+    uint32_t s = g.sub_begin();
     while (true) {
-        R z = g.next(R(-1), R(1));
-        R y = g.next(R(-1), R(1));
-        R x = g.next(R(-1), R(1));
+        R z = Rng<R>::sub_next(s, R(-1), R(1));
+        R y = Rng<R>::sub_next(s, R(-1), R(1));
+        R x = Rng<R>::sub_next(s, R(-1), R(1));
         V3<R> p = mk<R>(x, y, z);
         R lensq = len2(p);
         if (R(1e-160) < lensq && lensq <= R(1.0)) return divide<R>(p, m_sqrt(lensq));
     }
 }
 template <> RT_DEV V3<float> random_unit_vector<float>(Rng<float> &g) {
+    uint32_t s = g.sub_begin();
     while (true) {
-        float z = g.next(-1.f, 1.f);
-        float y = g.next(-1.f, 1.f);
-        float x = g.next(-1.f, 1.f);
+        float z = Rng<float>::sub_next(s, -1.f, 1.f);
+        float y = Rng<float>::sub_next(s, -1.f, 1.f);
+        float x = Rng<float>::sub_next(s, -1.f, 1.f);
         V3<float> p = mk<float>(x, y, z);
         float lensq = len2(p);
         if (1e-30f < lensq && lensq <= 1.0f) return scale<float>(__builtin_amdgcn_rsqf(lensq), p); // 1e-160 underflows float
@@ -1015,9 +1030,10 @@ template <class R> RT_DEV RayT<R> get_ray(const CameraT<R> &cam, int i, int j, i
     V3<R> origin = ld3(cam.center);
     if (cam.defocus_angle > R(0)) { // camera.h:285, vec3.h:106
         R dx, dy;
+        uint32_t s = g.sub_begin();
         while (true) {
-            dy = g.next(R(-1), R(1));
-            dx = g.next(R(-1), R(1));
+            dy = Rng<R>::sub_next(s, R(-1), R(1));
+            dx = Rng<R>::sub_next(s, R(-1), R(1));
             if (dx * dx + dy * dy + R(0) * R(0) < R(1)) break;
         }
         origin = ld3(cam.center) + scale<R>(dx, ld3(cam.ddu)) + scale<R>(dy, ld3(cam.ddv));
@@ -1040,10 +1056,26 @@ struct ShadeProf { unsigned long long last, sec[8]; };
         sp.sec[k] += t_ - sp.last;                                                                                     \
         sp.last = t_;                                                                                                  \
     } while (0)
+// leaf-trip sub-blocks: cycles, executions and lanes of the AABOX / MEDIUM / other code (actions 2..4 of the profile)
+#define RT_SUB_BEGIN()                                                                                                 \
+    unsigned long long t_sub = 0;                                                                                      \
+    if (leaf_trip) {                                                                                                   \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                    \
+        t_sub = __builtin_amdgcn_s_memtime();                                                                          \
+    }
+#define RT_SUB_END(k, mask)                                                                                            \
+    if (leaf_trip) {                                                                                                   \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                    \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                    \
+        if ((mask) != 0ull) { sub_cyc[k] += t_ - t_sub; sub_trips[k] += 1; sub_lanes[k] += popc64(mask); }             \
+        t_sub = t_;                                                                                                    \
+    }
 #else
 #define RT_SP_PARAM
 #define RT_SP_ARG
 #define RT_STAMP(k)
+#define RT_SUB_BEGIN()
+#define RT_SUB_END(k, mask)
 #endif
 
 // The part of camera::ray_color (camera.h:291-326) that follows world.hit(), written iteratively: radiance
@@ -1240,6 +1272,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     const unsigned long long t_wave0 = __builtin_amdgcn_s_memtime();
     ShadeProf sp{};
     unsigned long long sp_tail = 0, prof_idle = 0, prof_ready = 0, prof_all = 0, prof_tail = 0;
+    unsigned long long sub_cyc[A_COUNT] = {}, sub_trips[A_COUNT] = {}, sub_lanes[A_COUNT] = {};
 #endif
     // Work: an item = (8 x 2 pixel tile, chunk of the sample range) = 16 x samples UNITS, unit u = sample s0 + u / 16 of the
     // tile's pixel u % 16.  Lanes do not own pixels: a lane whose path has ended takes the next unit (wave-level dealing:
@@ -1299,8 +1332,9 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             // lane state = low bits of tv.hdr: the kind of the record at the cursor, K_READY (traversal finished, waiting to
             // be shaded) or K_IDLE (no unit)
             const int kind = tv.hdr & 15;
-            const bool is_box = kind == K_BOX, is_sph = kind == K_SPHERE, is_aab = kind == K_AABOX, is_med = kind == K_MEDIUM;
-            const bool is_oth = kind >= K_QUAD && kind < K_IDLE; // quad, triangle, moving sphere, instance boundary
+            // (a moving sphere is a sphere whose centre takes one more fetch and three fmas: it shares the sphere code)
+            const bool is_box = kind == K_BOX, is_sph = kind == K_SPHERE || kind == K_MSPHERE, is_aab = kind == K_AABOX, is_med = kind == K_MEDIUM;
+            const bool is_oth = kind >= K_QUAD && kind < K_IDLE && kind != K_MSPHERE; // quad, triangle, instance boundary, general medium
             const bool ready = kind == K_READY;
             const unsigned long long mb = lane_mask(is_box), ms = lane_mask(is_sph), ma = lane_mask(is_aab), mm = lane_mask(is_med),
                                      mo = lane_mask(is_oth), mr = lane_mask(ready);
@@ -1344,12 +1378,20 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             if (leaf_trip && ms != 0ull) {
                 if (is_sph) {
                     V3<R> cc = mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]);
-                    if constexpr (sizeof(R) == 8) cc = cc + scale<R>(ray.tm, mk<R>(R(0), R(0), R(0))); // center.at(time), sphere.h:30
+                    int next = tv.i + 2 * Pos<R>::unit;
+                    if (kind == K_MSPHERE) { // centre = c + time * d (sphere.h:30)
+                        const UnitT<R> u2 = mem.ld(next);
+                        cc = cc + scale<R>(ray.tm, mk<R>(u2.w[0], u2.w[1], u2.w[2]));
+                        next += Pos<R>::unit;
+                    } else if constexpr (sizeof(R) == 8) {
+                        cc = cc + scale<R>(ray.tm, mk<R>(R(0), R(0), R(0))); // the reference always evaluates center.at(time)
+                    }
                     R t;
                     if (sphere_t(cc, tv.u0.w[3], tv.o, tv.d, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx; }
-                    trav_goto(mem, tv, tv.i + 2 * Pos<R>::unit);
+                    trav_goto(mem, tv, next);
                 }
             }
+            RT_SUB_BEGIN();
             if (leaf_trip && ma != 0ull) {
                 if (is_aab) {
                     R t;
@@ -1357,6 +1399,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     trav_goto(mem, tv, tv.i + 2 * Pos<R>::unit);
                 }
             }
+            RT_SUB_END(2, ma);
             if (leaf_trip && mm != 0ull) {
                 if (is_med) {
                     auto mxi = [&](int node_id, int sel) {
@@ -1372,6 +1415,9 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     trav_goto(mem, tv, tv.i + 2 * Pos<R>::unit);
                 }
             }
+            RT_SUB_END(3, mm);
+            // (letting these few lanes -- final_scene: the light's quad, 4 per trip on average -- wait until 8 / 16 of them
+            // stand here: 762 -> 782 / 794 ms; a waiting lane is a lost lane)
             if (leaf_trip && mo != 0ull) {
                 if (is_oth) {
                     auto mxi = [&](int node_id, int sel) {
@@ -1382,6 +1428,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     trav_leaf_step<GEN_MEDIUM>(mem, sc, tv, ray, tmin, mxi);
                 }
             }
+            RT_SUB_END(4, mo);
             if (action == A_SHADE) {
                 if (ready) {
 #ifdef RT_PROFILE_ACTIONS
@@ -1562,9 +1609,9 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
 #ifdef RT_PROFILE_ACTIONS
     if (lane == 0) {
         for (int k = 0; k < A_COUNT; k++) {
-            atomicAdd(&counters[4 + 3 * k], prof_cyc[k]);
-            atomicAdd(&counters[5 + 3 * k], prof_trips[k]);
-            atomicAdd(&counters[6 + 3 * k], prof_lanes[k]);
+            atomicAdd(&counters[4 + 3 * k], prof_cyc[k] + sub_cyc[k]);
+            atomicAdd(&counters[5 + 3 * k], prof_trips[k] + sub_trips[k]);
+            atomicAdd(&counters[6 + 3 * k], prof_lanes[k] + sub_lanes[k]);
         }
         atomicAdd(&counters[3], __builtin_amdgcn_s_memtime() - t_wave0);
         for (int k = 0; k < 8; k++) atomicAdd(&counters[24 + k], sp.sec[k]);
