@@ -320,15 +320,12 @@ int enqueue_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, int
 
 void print_profile(rt_ctx *ctx, const unsigned long long *c) { // diagnostic builds (-DRT_PROFILE_*) fill counters[3..39]
     if (std::getenv("RT_AMD_PROFILE_ACTIONS")) {
-        const char *nm[6] = {"box", "leaf", "-", "-", "-", "shade"};
+        const char *nm[6] = {"box", "leaf", "leaf/aabox", "leaf/medium", "leaf/other", "shade+deal"};
         for (int k = 0; k < 6; k++)
-            std::fprintf(stderr, "[rt_amd profile] %-6s cycles %.4g (%.1f%% of wave time) trips %.4g cyc/trip %.1f lanes/trip %.1f\n",
+            std::fprintf(stderr, "[rt_amd profile] %-11s cycles %.4g (%.1f%% of wave time) trips %.4g cyc/trip %.1f lanes/trip %.1f\n",
                          nm[k], (double)c[4 + 3 * k], 100.0 * (double)c[4 + 3 * k] / (double)(c[3] ? c[3] : 1), (double)c[5 + 3 * k],
                          (double)c[4 + 3 * k] / (double)(c[5 + 3 * k] ? c[5 + 3 * k] : 1),
                          (double)c[6 + 3 * k] / (double)(c[5 + 3 * k] ? c[5 + 3 * k] : 1));
-        const char *sn[9] = {"rng begin", "finalize", "material+emit", "metal", "dielectric", "texture", "sample dir", "pdfs+weight", "tail (trav_begin / next_path)"};
-        for (int k = 0; k < 9; k++)
-            std::fprintf(stderr, "[rt_amd profile]   shade/%-30s %.1f%% of wave time\n", sn[k], 100.0 * (double)c[24 + k] / (double)(c[3] ? c[3] : 1));
         std::fprintf(stderr, "[rt_amd profile] per trip: %.1f lanes idle (item tail), %.1f lanes waiting for shading, of 64; %.1f%% of trips after the item's last unit was dealt\n",
                      (double)c[33] / (double)(c[35] ? c[35] : 1), (double)c[34] / (double)(c[35] ? c[35] : 1), 100.0 * (double)c[36] / (double)(c[35] ? c[35] : 1));
     }

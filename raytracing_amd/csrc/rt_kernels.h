@@ -178,6 +178,7 @@ template <class R> struct Rng {
         block++;
         have = 4;
     }
+    RT_DEV void begin_stream(uint32_t px, uint32_t s, uint32_t st) { pixel = px; sample = s; stream = st; block = 0; refill(); }
     RT_DEV void begin(uint32_t px, uint32_t s) { pixel = px; sample = s; stream = 0u; block = 0; refill(); }
     RT_DEV void begin_bounce(uint32_t px, uint32_t s, int bounce) {
         pixel = px; sample = s; stream = 0x80000000u | (uint32_t)bounce; block = 0; refill();
@@ -1046,16 +1047,6 @@ template <class R> RT_DEV RayT<R> get_ray(const CameraT<R> &cam, int i, int j, i
 }
 
 #ifdef RT_PROFILE_ACTIONS
-struct ShadeProf { unsigned long long last, sec[8]; };
-#define RT_SP_PARAM , ShadeProf &sp
-#define RT_SP_ARG , sp
-#define RT_STAMP(k)                                                                                                   \
-    do {                                                                                                               \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                    \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                    \
-        sp.sec[k] += t_ - sp.last;                                                                                     \
-        sp.last = t_;                                                                                                  \
-    } while (0)
 // leaf-trip sub-blocks: cycles, executions and lanes of the AABOX / MEDIUM / other code (actions 2..4 of the profile)
 #define RT_SUB_BEGIN()                                                                                                 \
     unsigned long long t_sub = 0;                                                                                      \
@@ -1071,34 +1062,38 @@ struct ShadeProf { unsigned long long last, sec[8]; };
         t_sub = t_;                                                                                                    \
     }
 #else
-#define RT_SP_PARAM
-#define RT_SP_ARG
-#define RT_STAMP(k)
 #define RT_SUB_BEGIN()
 #define RT_SUB_END(k, mask)
 #endif
 
 // The part of camera::ray_color (camera.h:291-326) that follows world.hit(), written iteratively: radiance
-// L += beta * (emitted | background), beta *= attenuation * scattering_pdf / pdf.  Returns false when the path ends.
+// L += beta * (emitted | background), beta *= attenuation * scattering_pdf / pdf -- in two halves, so that the render
+// kernel can deal new units to the lanes whose paths end BEFORE it runs the generator: one generator block then serves
+// the scattering lanes and the new camera rays alike.
+// shade_hit(): the hit record; returns false when the path ends here (no draw is needed for that: a miss, or a light --
+// every hit that scatters emits nothing (material.h:28-31), so the recursion's sum of emissions has exactly one non-zero
+// term, beta * (emitted | background), which is L).
 template <class R, bool ALL_LDS, class SC>
-RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SC &sc, const CameraT<R> &cam, RayT<R> &ray, R best_t, int best_off,
-                  int best_ctx, V3<R> &beta, V3<R> &L, Rng<R> &g RT_SP_PARAM) {
-    // L is written only when the path ends here: every hit that scatters emits nothing (material.h:28-31), so the
-    // recursion's sum of emissions has exactly one non-zero term, beta * (emitted | background).
+RT_DEV bool shade_hit(const Mem<R, ALL_LDS> &mem, const SC &sc, const CameraT<R> &cam, const RayT<R> &ray, R best_t, int best_off,
+                      int best_ctx, const V3<R> &beta, V3<R> &L, Hit<R> &h) {
     if (best_off < 0) { // camera.h:300
         L = beta * ld3(cam.background);
         return false;
     }
-    Hit<R> h = finalize(mem, sc, ray, best_t, best_off, best_ctx, false);
-    RT_STAMP(1);
+    h = finalize(mem, sc, ray, best_t, best_off, best_ctx, false);
     const MatT<R> m = sc.mat(h.mat);
-    V3<R> emitted = mk<R>(R(0), R(0), R(0));
     if (m.kind == RT_MAT_DIFFUSE_LIGHT) { // material.h:129
+        V3<R> emitted = mk<R>(R(0), R(0), R(0));
         if (h.front) emitted = tex_value(sc, m.tex, h.u, h.v, h.p);
         L = beta * emitted;
         return false; // material.h:28: no scatter
     }
-    RT_STAMP(2);
+    return true;
+}
+
+// shade_scatter(): material::scatter and the mixture pdf for a hit that shade_hit() let through; the next ray and beta.
+template <class R, class SC> RT_DEV void shade_scatter(const SC &sc, RayT<R> &ray, const Hit<R> &h, V3<R> &beta, Rng<R> &g) {
+    const MatT<R> m = sc.mat(h.mat);
     if (m.kind == RT_MAT_METAL) { // material.h:66
         V3<R> reflected = reflect(ray.d, h.n);
         V3<R> ruv = random_unit_vector(g);
@@ -1106,9 +1101,8 @@ RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SC &sc, const CameraT<R> &ca
         beta = beta * ld3(m.albedo);
         ray.o = h.p;
         ray.d = reflected;
-        return true;
+        return;
     }
-    RT_STAMP(3);
     if (m.kind == RT_MAT_DIELECTRIC) { // material.h:88
         R ri = h.front ? m_rcp(m.ior) : m.ior;
         V3<R> ud = unit(ray.d);
@@ -1126,19 +1120,16 @@ RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SC &sc, const CameraT<R> &ca
         // attenuation (1,1,1): beta unchanged up to a multiplication by one
         ray.o = h.p;
         ray.d = dir;
-        return true;
+        return;
     }
     // lambertian / isotropic: mixture of light sampling and BRDF sampling (camera.h:313-325, pdf.h:69-85)
-    RT_STAMP(4);
     const bool lambert = (m.kind == RT_MAT_LAMBERTIAN);
     V3<R> atten = tex_value(sc, m.tex, h.u, h.v, h.p);
-    RT_STAMP(5);
     V3<R> dir;
     int picked = -1;
     if (g.next() < R(0.5)) dir = light_random(sc, h.p, g, picked);
     else if (lambert) dir = Onb<R>(h.n).transform(random_cosine_direction(g)); // pdf.h:40
     else dir = random_unit_vector(g);                                          // pdf.h:25
-    RT_STAMP(6);
     R v0 = light_pdf(sc, h.p, dir, picked);
     R v1, spdf;
     if (lambert) {
@@ -1155,8 +1146,6 @@ RT_DEV bool shade(const Mem<R, ALL_LDS> &mem, const SC &sc, const CameraT<R> &ca
     beta = beta * scale<R>(wgt, atten);
     ray.o = h.p;
     ray.d = dir;
-    RT_STAMP(7);
-    return true;
 }
 
 // LDS accumulation of a finished path (wave scope: only this wave touches its accumulators).
@@ -1270,8 +1259,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
 #ifdef RT_PROFILE_ACTIONS
     unsigned long long prof_cyc[A_COUNT] = {}, prof_trips[A_COUNT] = {}, prof_lanes[A_COUNT] = {};
     const unsigned long long t_wave0 = __builtin_amdgcn_s_memtime();
-    ShadeProf sp{};
-    unsigned long long sp_tail = 0, prof_idle = 0, prof_ready = 0, prof_all = 0, prof_tail = 0;
+    unsigned long long prof_idle = 0, prof_ready = 0, prof_all = 0, prof_tail = 0;
     unsigned long long sub_cyc[A_COUNT] = {}, sub_trips[A_COUNT] = {}, sub_lanes[A_COUNT] = {};
 #endif
     // Work: an item = (8 x 2 pixel tile, chunk of the sample range) = 16 x samples UNITS, unit u = sample s0 + u / 16 of the
@@ -1429,155 +1417,158 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                 }
             }
             RT_SUB_END(4, mo);
-            if (action == A_SHADE) {
+            // The shading trip (and the trip that only deals, when nothing is in flight), in three steps:
+            //   1. every lane whose traversal has finished gets its hit record; a path that ends here -- a miss, a light --
+            //      needs no draw: its sample is added and the lane is free;
+            //   2. free lanes are dealt their next unit;
+            //   3. ONE generator block per lane that now starts a ray -- bounce b's block for the lanes that scatter, the
+            //      camera block for the new units -- then material::scatter / get_ray, and one trav_begin for both.
+            // (Dealing behind the scattering code, with a generator call and a trav_begin of its own: 739 -> see DESIGN.md)
+            if (action == A_SHADE || action == A_DEAL) {
+                // a finished path: add the sample to its pixel's accumulator; the lane asks for its next unit
+                auto add_sample = [&](const V3<R> &L) {
+                    Cell *const px = acc + pp * 3;
+                    if constexpr (sizeof(R) == 4) {
+                        const float lv[3] = {L.x, L.y, L.z};
+                        // the usual sample: three finite values in [0, 256) -> v * 2^24 fits 32 bits, one fma + one
+                        // conversion per channel.  (Which branch a sample takes depends on the sample alone.)
+                        const float sum = (L.x + L.y) + L.z; // NaN if any channel is
+                        if (sum < 256.0f && fminf(fminf(L.x, L.y), L.z) >= 0.0f) {
+#pragma unroll
+                            for (int c = 0; c < 3; c++) lds_add(px + c, (unsigned long long)(unsigned)fmaf(lv[c], 16777216.0f, 0.5f));
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 3; c++) {
+                                if (lv[c] != lv[c]) { // NaN: flag the cell (0/0 weights, a light sphere seen from inside)
+                                    const int bit = (pp & (TPX - 1)) * 3 + c;
+                                    (void)__hip_atomic_fetch_or(&ws[WS_NAN + (pp >> TSH) * LdsLayout<R>::nan_words + (bit >> 5)], 1 << (bit & 31),
+                                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                } else {
+                                    lds_add(px + c, to_fixed(__builtin_amdgcn_fmed3f(lv[c], 0.0f, RT_FX_CLAMP)));
+                                }
+                            }
+                        }
+                    } else {
+                        lds_add(px, L.x); lds_add(px + 1, L.y); lds_add(px + 2, L.z);
+                    }
+                    tv.hdr = K_IDLE;
+                };
+                // ---- 1
+                Hit<R> h;
+                bool scatter = false;
                 if (ready) {
-#ifdef RT_PROFILE_ACTIONS
-                    sp.last = __builtin_amdgcn_s_memtime();
-#endif
-                    Rng<R> g;
-                    g.k0 = a.k0;
-                    g.k1 = a.k1;
-                    g.begin_bounce(pixel, (uint32_t)smp, bounce);
-                    med_xi = g.fifth(); // for the ray this shading may start
-                    RT_STAMP(0);
                     if constexpr (sizeof(R) == 4) { // traversal ended in the world frame: tv holds the world-space ray
                         ray.o = tv.o;
                         ray.d = tv.d;
                     }
                     V3<R> L;
-                    bool alive = shade(mem, sc, cam, ray, tv.best_t, tv.best_off, tv.best_ctx, beta, L, g RT_SP_ARG);
-#ifdef RT_PROFILE_ACTIONS
-                    sp.last = __builtin_amdgcn_s_memtime();
-#endif
-                    bounce++;
-                    if (alive && bounce == cam.max_depth) { // depth exhausted: the recursion returns 0 here (camera.h:294-295)
-                        L = beta * mk<R>(R(0), R(0), R(0));
-                        alive = false;
-                    }
-                    if (alive) {
-                        rays++;
-                        trav_begin(mem, tv, ray);
-                    } else {
-                        Cell *const px = acc + pp * 3;
-                        if constexpr (sizeof(R) == 4) {
-                            const float lv[3] = {L.x, L.y, L.z};
-                            // the usual sample: three finite values in [0, 256) -> v * 2^24 fits 32 bits, one fma + one
-                            // conversion per channel.  (Which branch a sample takes depends on the sample alone.)
-                            const float sum = (L.x + L.y) + L.z; // NaN if any channel is
-                            if (sum < 256.0f && fminf(fminf(L.x, L.y), L.z) >= 0.0f) {
+                    scatter = shade_hit(mem, sc, cam, ray, tv.best_t, tv.best_off, tv.best_ctx, beta, L, h);
+                    if (!scatter) add_sample(L);
+                }
+                // ---- 2
+                bool fresh = false; // this lane was dealt a unit in this trip: pixel (fi, fj), sample smp
+                int fi = 0, fj = 0;
+                const int kind0 = tv.hdr & 15;
+                const unsigned long long midle = lane_mask(kind0 == K_IDLE);
+                if (midle && units_left >= 0) {
+                    if (units_left == 0) {
+                        // the current item has no units left: take an accumulator slot none of whose paths is still in flight (the
+                        // first one in ring order: a slot that waits for one long path does not hold up the others), store the item
+                        // that used it and fetch a new item into it
+                        unsigned free_slots = (1u << NS) - 1u;
 #pragma unroll
-                                for (int c = 0; c < 3; c++) lds_add(px + c, (unsigned long long)(unsigned)fmaf(lv[c], 16777216.0f, 0.5f));
+                        for (int k = 0; k < NS; k++)
+                            if (lane_mask(kind0 != K_IDLE && (pp >> TSH) == k)) free_slots &= ~(1u << k);
+                        const int first = wsl(WS_CUR_SLOT) + 1; // 1 .. NS
+                        const unsigned rot = ((free_slots >> first) | (free_slots << (NS - first))) & ((1u << NS) - 1u);
+                        if (rot) {
+                            int t = first + __builtin_ctz(rot);
+                            t = t >= NS ? t - NS : t;
+                            const bool t_valid = wsl(4 * t + WS_SLOT_VALID) != 0;
+                            if (t_valid) flush(t, wsl(4 * t + WS_SLOT_I0), wsl(4 * t + WS_SLOT_J0), wsl(4 * t + WS_SLOT_CHUNK));
+                            int item = 0;
+                            if (lane == 0) item = (int)atomicAdd(&counters[1], 1ull);
+                            item = __builtin_amdgcn_readfirstlane(item);
+                            const int n_tiles = a.tiles_x * a.tiles_y;
+                            const bool got = item < n_tiles * a.n_chunks; // the cursor is finite: every wave sees its end
+                            const int chunk = item / n_tiles, tile = item - chunk * n_tiles;
+                            const int tj = tile / a.tiles_x, ti = tile - tj * a.tiles_x;
+                            int s0, s1;
+                            if (a.chunk_size > 0) {
+                                s0 = a.s_begin + chunk * a.chunk_size;
+                                s1 = s0 + a.chunk_size;
+                                if (s1 > a.s_end) s1 = a.s_end;
                             } else {
-#pragma unroll
-                                for (int c = 0; c < 3; c++) {
-                                    if (lv[c] != lv[c]) { // NaN: flag the cell (0/0 weights, a light sphere seen from inside)
-                                        const int bit = (pp & (TPX - 1)) * 3 + c;
-                                        (void)__hip_atomic_fetch_or(&ws[WS_NAN + (pp >> TSH) * LdsLayout<R>::nan_words + (bit >> 5)], 1 << (bit & 31),
-                                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                                    } else {
-                                        lds_add(px + c, to_fixed(__builtin_amdgcn_fmed3f(lv[c], 0.0f, RT_FX_CLAMP)));
-                                    }
+                                s0 = a.chunk_start[got ? chunk : 0];
+                                s1 = a.chunk_start[got ? chunk + 1 : 0];
+                            }
+                            const int n_new = got && cam.max_depth > 0 ? (s1 - s0) << TSH : 0; // max_depth <= 0: every sample is black (camera.h:294)
+                            if (lane == 0) {
+                                ws[4 * t + WS_SLOT_I0] = ti * 8; ws[4 * t + WS_SLOT_J0] = tj * LdsLayout<R>::tile_h; ws[4 * t + WS_SLOT_CHUNK] = chunk;
+                                ws[4 * t + WS_SLOT_VALID] = got ? 1 : 0;
+                                ws[WS_CUR_SLOT] = t; ws[WS_CUR_S0] = s0; ws[WS_N_UNITS] = n_new;
+                            }
+                            units_left = got ? n_new : -1;
+                        }
+                    }
+                    if (units_left > 0) {
+                        // deal units to the idle lanes: rank among the asking lanes + the item's cursor
+                        const int cur_slot = wsl(WS_CUR_SLOT), cur_s0 = wsl(WS_CUR_S0), n_item_units = wsl(WS_N_UNITS);
+                        const int cur_i0 = wsl(4 * cur_slot + WS_SLOT_I0), cur_j0 = wsl(4 * cur_slot + WS_SLOT_J0);
+                        const int slot6 = cur_slot << TSH;
+                        int next_unit = n_item_units - units_left;
+                        bool need = kind0 == K_IDLE;
+                        unsigned long long m = midle;
+                        do {
+                            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                            const int un = next_unit + rank;
+                            if (need && un < n_item_units) {
+                                const int p = un & (TPX - 1);
+                                const int i = cur_i0 + (p & 7), j = cur_j0 + (p >> 3);
+                                if (i < cam.W && j < cam.H) { // (units of pixels beyond the image edge are skipped)
+                                    need = false;
+                                    fresh = true;
+                                    fi = i;
+                                    fj = j;
+                                    pp = p | slot6;
+                                    pixel = (uint32_t)(j * cam.W + i);
+                                    smp = cur_s0 + (un >> TSH);
                                 }
                             }
-                        } else {
-                            lds_add(px, L.x); lds_add(px + 1, L.y); lds_add(px + 2, L.z);
-                        }
-                        tv.hdr = K_IDLE; // asks for its next unit at the top of the loop
+                            next_unit += popc64(m);
+                            m = lane_mask(need);
+                        } while (m && next_unit < n_item_units);
+                        units_left = next_unit < n_item_units ? n_item_units - next_unit : 0;
                     }
                 }
-#ifdef RT_PROFILE_ACTIONS
-                {
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    sp_tail += __builtin_amdgcn_s_memtime() - sp.last;
-                }
-#endif
-            }
-            // units for the lanes without one: after a shading trip (paths have ended) or when nothing is in flight
-            if (action == A_SHADE || action == A_DEAL) {
-            const int kind0 = tv.hdr & 15;
-            const unsigned long long midle = lane_mask(kind0 == K_IDLE);
-            if (midle && units_left >= 0) {
-                if (units_left == 0) {
-                // the current item has no units left: take an accumulator slot none of whose paths is still in flight (the
-                // first one in ring order: a slot that waits for one long path does not hold up the others), store the item
-                // that used it and fetch a new item into it
-                unsigned free_slots = (1u << NS) - 1u;
-#pragma unroll
-                for (int k = 0; k < NS; k++)
-                    if (lane_mask(kind0 != K_IDLE && (pp >> TSH) == k)) free_slots &= ~(1u << k);
-                const int first = wsl(WS_CUR_SLOT) + 1; // 1 .. NS
-                const unsigned rot = ((free_slots >> first) | (free_slots << (NS - first))) & ((1u << NS) - 1u);
-                if (rot) {
-                    int t = first + __builtin_ctz(rot);
-                    t = t >= NS ? t - NS : t;
-                    const bool t_valid = wsl(4 * t + WS_SLOT_VALID) != 0;
-                    if (t_valid) flush(t, wsl(4 * t + WS_SLOT_I0), wsl(4 * t + WS_SLOT_J0), wsl(4 * t + WS_SLOT_CHUNK));
-                    int item = 0;
-                    if (lane == 0) item = (int)atomicAdd(&counters[1], 1ull);
-                    item = __builtin_amdgcn_readfirstlane(item);
-                    const int n_tiles = a.tiles_x * a.tiles_y;
-                    const bool got = item < n_tiles * a.n_chunks; // the cursor is finite: every wave sees its end
-                    const int chunk = item / n_tiles, tile = item - chunk * n_tiles;
-                    const int tj = tile / a.tiles_x, ti = tile - tj * a.tiles_x;
-                    int s0, s1;
-                    if (a.chunk_size > 0) {
-                        s0 = a.s_begin + chunk * a.chunk_size;
-                        s1 = s0 + a.chunk_size;
-                        if (s1 > a.s_end) s1 = a.s_end;
+                // ---- 3
+                if (scatter || fresh) {
+                    if (fresh) bounce = 0;
+                    Rng<R> g;
+                    g.k0 = a.k0;
+                    g.k1 = a.k1;
+                    g.begin_stream(pixel, (uint32_t)smp, fresh ? 0u : (0x80000000u | (uint32_t)bounce));
+                    med_xi = g.fifth(); // for the ray that starts now
+                    if (fresh) {
+                        int sj = (int)((float)smp * (float)cam.recip_sqrt_spp); // s / sqrt_spp, s % sqrt_spp without an integer division
+                        int si = smp - sj * cam.sqrt_spp;
+                        if (si < 0) { sj--; si += cam.sqrt_spp; }
+                        if (si >= cam.sqrt_spp) { sj++; si -= cam.sqrt_spp; }
+                        ray = get_ray(cam, fi, fj, si, sj, g);
+                        beta = mk<R>(R(1), R(1), R(1));
                     } else {
-                        s0 = a.chunk_start[got ? chunk : 0];
-                        s1 = a.chunk_start[got ? chunk + 1 : 0];
-                    }
-                    const int n_new = got && cam.max_depth > 0 ? (s1 - s0) << TSH : 0; // max_depth <= 0: every sample is black (camera.h:294)
-                    if (lane == 0) {
-                        ws[4 * t + WS_SLOT_I0] = ti * 8; ws[4 * t + WS_SLOT_J0] = tj * LdsLayout<R>::tile_h; ws[4 * t + WS_SLOT_CHUNK] = chunk;
-                        ws[4 * t + WS_SLOT_VALID] = got ? 1 : 0;
-                        ws[WS_CUR_SLOT] = t; ws[WS_CUR_S0] = s0; ws[WS_N_UNITS] = n_new;
-                    }
-                    units_left = got ? n_new : -1;
-                }
-                }
-                if (units_left > 0) {
-                    // deal units to the idle lanes: rank among the asking lanes + the item's cursor
-                    const int cur_slot = wsl(WS_CUR_SLOT), cur_s0 = wsl(WS_CUR_S0), n_item_units = wsl(WS_N_UNITS);
-                    const int cur_i0 = wsl(4 * cur_slot + WS_SLOT_I0), cur_j0 = wsl(4 * cur_slot + WS_SLOT_J0);
-                    const int slot6 = cur_slot << TSH;
-                    int next_unit = n_item_units - units_left;
-                    bool need = kind0 == K_IDLE;
-                    unsigned long long m = midle;
-                    do {
-                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                        const int un = next_unit + rank;
-                        if (need && un < n_item_units) {
-                            const int p = un & (TPX - 1);
-                            const int i = cur_i0 + (p & 7), j = cur_j0 + (p >> 3);
-                            if (i < cam.W && j < cam.H) { // (units of pixels beyond the image edge are skipped)
-                                need = false;
-                                pp = p | slot6;
-                                pixel = (uint32_t)(j * cam.W + i);
-                                smp = cur_s0 + (un >> TSH);
-                                int sj = (int)((float)smp * (float)cam.recip_sqrt_spp); // s / sqrt_spp, s % sqrt_spp without an integer division
-                                int si = smp - sj * cam.sqrt_spp;
-                                if (si < 0) { sj--; si += cam.sqrt_spp; }
-                                if (si >= cam.sqrt_spp) { sj++; si -= cam.sqrt_spp; }
-                                Rng<R> g;
-                                g.k0 = a.k0;
-                                g.k1 = a.k1;
-                                g.begin(pixel, (uint32_t)smp);
-                                med_xi = g.fifth();
-                                ray = get_ray(cam, i, j, si, sj, g);
-                                beta = mk<R>(R(1), R(1), R(1));
-                                bounce = 0;
-                                rays++;
-                                trav_begin(mem, tv, ray);
-                            }
+                        shade_scatter(sc, ray, h, beta, g);
+                        bounce++;
+                        if (bounce == cam.max_depth) { // depth exhausted: the recursion returns 0 here (camera.h:294-295)
+                            add_sample(beta * mk<R>(R(0), R(0), R(0)));
+                            scatter = false; // (the lane gets its next unit in the next shading trip)
                         }
-                        next_unit += popc64(m);
-                        m = lane_mask(need);
-                    } while (m && next_unit < n_item_units);
-                    units_left = next_unit < n_item_units ? n_item_units - next_unit : 0;
+                    }
+                    if (fresh || scatter) {
+                        rays++;
+                        trav_begin(mem, tv, ray);
+                    }
                 }
-            }
             }
 #ifdef RT_PROFILE_ACTIONS
             { // diagnostic build only: cycles, trips and active lanes per action -> counters[4 + 3*action ...]
@@ -1614,8 +1605,6 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             atomicAdd(&counters[6 + 3 * k], prof_lanes[k] + sub_lanes[k]);
         }
         atomicAdd(&counters[3], __builtin_amdgcn_s_memtime() - t_wave0);
-        for (int k = 0; k < 8; k++) atomicAdd(&counters[24 + k], sp.sec[k]);
-        atomicAdd(&counters[32], sp_tail);
         atomicAdd(&counters[33], prof_idle);
         atomicAdd(&counters[34], prof_ready);
         atomicAdd(&counters[35], prof_all);
