@@ -677,7 +677,7 @@ template <class R> class Flattener {
         switch (n.kind) {
         case RT_NODE_BVH: {
             const bool twice = n.b == n.a && !in_baked && contains_medium(n.a, 0); // see emit(): the reference hits a span-1 child twice
-            if (twice && dup >= (1 << 14)) return fail(RT_ERR_UNSUPPORTED, "constant_medium below more than 14 nested span-1 bvh_nodes");
+            if (twice && dup >= 64) return fail(RT_ERR_UNSUPPORTED, "constant_medium below more than 6 nested span-1 bvh_nodes");
             int rc = collect(n.a, ctx, x, in_baked, twice ? 2 * dup : dup, rdepth + 1, out);
             if (rc) return rc;
             if (n.b != n.a) return collect(n.b, ctx, x, in_baked, dup, rdepth + 1, out);
@@ -930,7 +930,7 @@ template <class R> class Flattener {
             // copies told apart by cur_dup_ (which keys their draws).
             const bool twice = n.b == n.a && contains_medium(n.a, 0);
             const int dup = cur_dup_;
-            if (twice && dup >= (1 << 14)) return fail(RT_ERR_UNSUPPORTED, "constant_medium below more than 14 nested span-1 bvh_nodes");
+            if (twice && dup >= 64) return fail(RT_ERR_UNSUPPORTED, "constant_medium below more than 6 nested span-1 bvh_nodes");
             if (twice) cur_dup_ = 2 * dup;
             int rc = emit(n.a, ctx, rdepth + 1);
             if (rc) return rc;
@@ -949,7 +949,7 @@ template <class R> class Flattener {
             if (fuse_ && match_box(id, lo, hi, mat, face_id, outward)) {
                 const int off = push_units(2, id);
                 f_.stream[off] = UnitT<R>{{F(lo[0]), F(hi[0]), F(lo[1]), F(hi[1])}};
-                f_.stream[off + 1] = UnitT<R>{{F(lo[2]), F(hi[2]), I(mat), I(make_hdr(K_AABOX, outward))}};
+                f_.stream[off + 1] = UnitT<R>{{F(lo[2]), F(hi[2]), I(mat), I(make_hdr(K_AABOX, outward, ctx))}};
                 f_.cold[off] = UnitT<R>{{I(face_id[0]), I(face_id[1]), I(face_id[2]), I(face_id[3])}};
                 f_.cold[off + 1] = UnitT<R>{{I(face_id[4]), I(face_id[5]), I(0), I(0)}};
                 f_.n_fused_boxes++;
@@ -979,6 +979,7 @@ template <class R> class Flattener {
             x.parent = ctx;
             x.depth = pdepth + 1;
             int c = (int)f_.xforms.size();
+            if (c >= (1 << 20)) return fail(RT_ERR_UNSUPPORTED, "more than 2^20 translate / rotate_y instances");
             for (int k = 0; k < pdepth; k++) x.chain[k] = parent.chain[k];
             x.chain[pdepth] = c;
             if (n.kind == RT_NODE_TRANSLATE) {
@@ -1006,14 +1007,14 @@ template <class R> class Flattener {
                 if (contains_medium(n.a, 0)) return fail(RT_ERR_UNSUPPORTED, "constant_medium inside the boundary of a constant_medium");
                 const int off = push_units(2, id);
                 f_.stream[off] = UnitT<R>{{I(0), R(0), R(0), R(0)}};
-                f_.stream[off + 1] = UnitT<R>{{F(n.p[0]), I(n.b), I(id), I(make_hdr(K_MEDIUM_GEN, medium_payload(id)))}};
+                f_.stream[off + 1] = UnitT<R>{{F(n.p[0]), I(n.b), I(id), I(make_hdr(K_MEDIUM_GEN, medium_payload(id), ctx))}};
                 pending_.push_back(Pending{off, n.a, ctx});
                 return RT_OK;
             }
             const rt_sphere &s = d_.spheres[b.a];
             const int off = push_units(2, id);
             f_.stream[off] = UnitT<R>{{F(s.center[0]), F(s.center[1]), F(s.center[2]), F(s.radius)}};
-            f_.stream[off + 1] = UnitT<R>{{F(n.p[0]), I(n.b), I(id), I(make_hdr(K_MEDIUM, medium_payload(id)))}};
+            f_.stream[off + 1] = UnitT<R>{{F(n.p[0]), I(n.b), I(id), I(make_hdr(K_MEDIUM, medium_payload(id), ctx))}};
             return RT_OK;
         }
         case RT_NODE_SPHERE: {
@@ -1022,7 +1023,7 @@ template <class R> class Flattener {
             const bool moving = s.dcenter[0] != 0 || s.dcenter[1] != 0 || s.dcenter[2] != 0;
             const int off = push_units(moving ? 3 : 2, id);
             f_.stream[off] = UnitT<R>{{F(s.center[0]), F(s.center[1]), F(s.center[2]), F(s.radius)}};
-            f_.stream[off + 1] = UnitT<R>{{I(s.mat), I(0), I(0), I(make_hdr(moving ? K_MSPHERE : K_SPHERE, 0))}};
+            f_.stream[off + 1] = UnitT<R>{{I(s.mat), I(0), I(0), I(make_hdr(moving ? K_MSPHERE : K_SPHERE, 0, ctx))}};
             if (moving) f_.stream[off + 2] = UnitT<R>{{F(s.dcenter[0]), F(s.dcenter[1]), F(s.dcenter[2]), R(0)}};
             return RT_OK;
         }
@@ -1031,7 +1032,7 @@ template <class R> class Flattener {
             if (q.mat < 0) return fail(RT_ERR_INVALID, "world quad without material");
             const int off = push_units(5, id);
             f_.stream[off] = UnitT<R>{{F(q.normal[0]), F(q.normal[1]), F(q.normal[2]), F(q.D)}};
-            f_.stream[off + 1] = UnitT<R>{{F(q.Q[0]), F(q.Q[1]), F(q.Q[2]), I(make_hdr(K_QUAD, 0))}};
+            f_.stream[off + 1] = UnitT<R>{{F(q.Q[0]), F(q.Q[1]), F(q.Q[2]), I(make_hdr(K_QUAD, 0, ctx))}};
             f_.stream[off + 2] = UnitT<R>{{F(q.u[0]), F(q.u[1]), F(q.u[2]), I(q.mat)}};
             f_.stream[off + 3] = UnitT<R>{{F(q.v[0]), F(q.v[1]), F(q.v[2]), F(q.area)}};
             f_.stream[off + 4] = UnitT<R>{{F(q.w[0]), F(q.w[1]), F(q.w[2]), R(0)}};
@@ -1045,7 +1046,7 @@ template <class R> class Flattener {
             const double e2[3] = {t.v2[0] - t.v0[0], t.v2[1] - t.v0[1], t.v2[2] - t.v0[2]};
             const int off = push_units(3, id);
             f_.stream[off] = UnitT<R>{{F(t.v0[0]), F(t.v0[1]), F(t.v0[2]), F(e1[0])}};
-            f_.stream[off + 1] = UnitT<R>{{F(e1[1]), F(e1[2]), F(e2[0]), I(make_hdr(K_TRI, 0))}};
+            f_.stream[off + 1] = UnitT<R>{{F(e1[1]), F(e1[2]), F(e2[0]), I(make_hdr(K_TRI, 0, ctx))}};
             f_.stream[off + 2] = UnitT<R>{{F(e2[1]), F(e2[2]), I(t.mat), I(t.cull)}};
             f_.cold[off] = UnitT<R>{{F(t.normal[0]), F(t.normal[1]), F(t.normal[2]), I(id)}};
             return RT_OK;

@@ -552,8 +552,6 @@ template <class R> struct Trav {
     V3<R> noi;       // float path: -o * inv, so that a slab distance is one fma (b * inv + noi)
     R best_t;
     int best_off; // position (byte offset) of the winning record, -1 = miss
-    int best_ctx;
-    int ctx;
     int i; // cursor (byte offset of the record)
     // the record at the cursor
     UnitT<R> u0, u1;
@@ -577,8 +575,6 @@ RT_DEV void trav_begin(const Mem<R, ALL_LDS> &mem, Trav<R> &tv, const RayT<R> &w
     if constexpr (sizeof(R) == 4) tv.noi = -(tv.o * tv.inv);
     tv.best_t = Const<R>::inf;
     tv.best_off = -1;
-    tv.best_ctx = 0;
-    tv.ctx = 0;
     trav_goto(mem, tv, 0);
 }
 
@@ -607,17 +603,17 @@ RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SC &sc, Trav<R> &tv
             cc = cc + scale<R>(world.tm, mk<R>(R(0), R(0), R(0))); // the reference always evaluates center.at(time)
         }
         R t;
-        if (sphere_t(cc, tv.u0.w[3], tv.o, tv.d, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = i; tv.best_ctx = tv.ctx; }
+        if (sphere_t(cc, tv.u0.w[3], tv.o, tv.d, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = i; }
     } else if (kind == K_AABOX) {
         R t;
-        if (aabox_t(tv.u0, tv.u1, tv.o, tv.inv, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = i; tv.best_ctx = tv.ctx; }
+        if (aabox_t(tv.u0, tv.u1, tv.o, tv.inv, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = i; }
     } else if (kind == K_QUAD) {
         const UnitT<R> u2 = mem.ld(i + 2 * U), u3 = mem.ld(i + 3 * U), u4 = mem.ld(i + 4 * U);
         R t, al, be;
         if (quad_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], mk<R>(tv.u1.w[0], tv.u1.w[1], tv.u1.w[2]),
                    mk<R>(u2.w[0], u2.w[1], u2.w[2]), mk<R>(u3.w[0], u3.w[1], u3.w[2]), mk<R>(u4.w[0], u4.w[1], u4.w[2]), tv.o, tv.d,
                    tmin, tv.best_t, t, al, be)) {
-            tv.best_t = t; tv.best_off = i; tv.best_ctx = tv.ctx;
+            tv.best_t = t; tv.best_off = i;
         }
         next = i + 5 * U;
     } else if (kind == K_TRI) {
@@ -626,14 +622,14 @@ RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SC &sc, Trav<R> &tv
         float u, v;
         if (tri_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), mk<R>(tv.u0.w[3], tv.u1.w[0], tv.u1.w[1]),
                   mk<R>(tv.u1.w[2], u2.w[0], u2.w[1]), ldi(u2.w[3]), tv.o, tv.d, tmin, tv.best_t, t, u, v)) {
-            tv.best_t = t; tv.best_off = i; tv.best_ctx = tv.ctx;
+            tv.best_t = t; tv.best_off = i;
         }
         next = i + 3 * U;
     } else if (kind == K_MEDIUM) {
         R t;
-        if (medium_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], tv.u1.w[0], ldi(tv.u1.w[2]), tv.hdr >> 4, tv.o, tv.d,
+        if (medium_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], tv.u1.w[0], ldi(tv.u1.w[2]), hdr_payload(tv.hdr), tv.o, tv.d,
                      tmin, tv.best_t, medium_xi, t)) {
-            tv.best_t = t; tv.best_off = i; tv.best_ctx = tv.ctx;
+            tv.best_t = t; tv.best_off = i;
         }
     } else if (GM && kind == K_MEDIUM_GEN) {
         if constexpr (GM) {
@@ -645,7 +641,7 @@ RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SC &sc, Trav<R> &tv
             auto boundary_hit = [&](R lo, R &t_hit) {
                 Trav<R> s;
                 s.o = tv.o; s.d = tv.d; s.inv = tv.inv; s.noi = tv.noi;
-                s.best_t = Const<R>::inf; s.best_off = -1; s.best_ctx = tv.ctx; s.ctx = tv.ctx;
+                s.best_t = Const<R>::inf; s.best_off = -1;
                 trav_goto(mem, s, sub_off);
                 while ((s.hdr & 15) != K_READY) {
                     if ((s.hdr & 15) == K_BOX) trav_box_step(mem, s, lo);
@@ -656,17 +652,15 @@ RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SC &sc, Trav<R> &tv
             };
             R t1, t2, t;
             if (boundary_hit(-Const<R>::inf, t1) && boundary_hit(t1 + R(0.0001), t2) &&
-                medium_span(t1, t2, tv.u1.w[0], ldi(tv.u1.w[2]), tv.hdr >> 4, tv.d, tmin, tv.best_t, medium_xi, t)) {
-                tv.best_t = t; tv.best_off = i; tv.best_ctx = tv.ctx;
+                medium_span(t1, t2, tv.u1.w[0], ldi(tv.u1.w[2]), hdr_payload(tv.hdr), tv.d, tmin, tv.best_t, medium_xi, t)) {
+                tv.best_t = t; tv.best_off = i;
             }
         }
     } else if (kind == K_XF_ENTER) {
         xf_apply(ldi(tv.u1.w[0]), tv.u0.w[0], tv.u0.w[1], tv.u0.w[2], tv.o, tv.d);
         tv.inv = inv_dir_trav(tv.d);
         if constexpr (sizeof(R) == 4) tv.noi = -(tv.o * tv.inv);
-        tv.ctx = ldi(tv.u1.w[1]);
     } else if (kind == K_XF_EXIT) {
-        tv.ctx = ldi(tv.u1.w[1]);
         if constexpr (sizeof(R) == 4) {
             // leave the frame by the inverse transform: the world-space ray need not stay in registers during traversal
             if (ldi(tv.u1.w[0]) == XF_TRANSLATE) {
@@ -679,7 +673,7 @@ RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SC &sc, Trav<R> &tv
             tv.inv = inv_dir_trav(tv.d);
             tv.noi = -(tv.o * tv.inv);
         } else { // the reference's outer ray is untouched by the instance (hittable.h:53-65): restore it exactly
-            const RayT<R> r = ray_in_ctx(sc, world, tv.ctx);
+            const RayT<R> r = ray_in_ctx(sc, world, ldi(tv.u1.w[1])); // the frame outside the instance
             tv.o = r.o;
             tv.d = r.d;
             tv.inv = inv_dir(r.d);
@@ -708,8 +702,7 @@ template <class R> RT_DEV void sphere_uv(V3<R> p, R &u, R &v) { // sphere.h:89
 
 // Re-derive the full hit record of the winning primitive (same arithmetic as the reference's success path).
 template <class R, bool ALL_LDS, class SC>
-RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SC &sc, const RayT<R> &world, R best_t, int best_off, int best_ctx,
-                       bool want_all) {
+RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SC &sc, const RayT<R> &world, R best_t, int best_off, bool want_all) {
     Hit<R> h;
     h.t = best_t;
     h.off = best_off;
@@ -720,6 +713,7 @@ RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SC &sc, const RayT<R> &
     const UnitT<R> u0 = mem.ld(best_off), u1 = mem.ld(best_off + U);
     const int hdr = ldi(u1.w[3]);
     h.kind = hdr & 15;
+    const int best_ctx = hdr_ctx(hdr);
     const RayT<R> r = ray_in_ctx(sc, world, best_ctx);
     h.p = ray_at(r, best_t);
     if (h.kind == K_SPHERE || h.kind == K_MSPHERE) {
@@ -754,7 +748,7 @@ RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SC &sc, const RayT<R> &
         const int axis = face >> 1;
         const R sgn = (face & 1) ? R(1) : R(-1); // outward direction of this face
         V3<R> outward = mk<R>(axis == 0 ? sgn : R(0), axis == 1 ? sgn : R(0), axis == 2 ? sgn : R(0));
-        const bool stored_outward = ((hdr >> 4) >> face) & 1;
+        const bool stored_outward = (hdr_payload(hdr) >> face) & 1;
         const V3<R> n = stored_outward ? outward : -outward; // the quad's own normal (quad.h:15)
         h.front = dot(r.d, n) < R(0);
         h.n = h.front ? n : -n;
@@ -1075,12 +1069,12 @@ template <class R> RT_DEV RayT<R> get_ray(const CameraT<R> &cam, int i, int j, i
 // term, beta * (emitted | background), which is L).
 template <class R, bool ALL_LDS, class SC>
 RT_DEV bool shade_hit(const Mem<R, ALL_LDS> &mem, const SC &sc, const CameraT<R> &cam, const RayT<R> &ray, R best_t, int best_off,
-                      int best_ctx, const V3<R> &beta, V3<R> &L, Hit<R> &h) {
+                      const V3<R> &beta, V3<R> &L, Hit<R> &h) {
     if (best_off < 0) { // camera.h:300
         L = beta * ld3(cam.background);
         return false;
     }
-    h = finalize(mem, sc, ray, best_t, best_off, best_ctx, false);
+    h = finalize(mem, sc, ray, best_t, best_off, false);
     const MatT<R> m = sc.mat(h.mat);
     if (m.kind == RT_MAT_DIFFUSE_LIGHT) { // material.h:129
         V3<R> emitted = mk<R>(R(0), R(0), R(0));
@@ -1361,6 +1355,9 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     if (popc64(lane_mask(at_box)) < RT_BOX_REPEAT_MIN) break;
                 }
             }
+            // (Tried: d.d and its reciprocal kept with the ray instead of recomputed by every sphere and medium test -- two more
+            // registers of loop-carried state, 711 -> 721 ms; spheres and sphere-bounded media sharing one solve of the
+            // quadratic in one block -> 736 ms.  The short separate blocks below are what the scheduler handles best.)
             // the leaf trip: one step of every kind that has lanes (a second step for lanes that meet the same kind again --
             // the leaves of a BVH node are neighbours in the stream -- measured slower once the kinds share a trip)
             if (leaf_trip && ms != 0ull) {
@@ -1375,7 +1372,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         cc = cc + scale<R>(ray.tm, mk<R>(R(0), R(0), R(0))); // the reference always evaluates center.at(time)
                     }
                     R t;
-                    if (sphere_t(cc, tv.u0.w[3], tv.o, tv.d, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx; }
+                    if (sphere_t(cc, tv.u0.w[3], tv.o, tv.d, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; }
                     trav_goto(mem, tv, next);
                 }
             }
@@ -1383,7 +1380,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             if (leaf_trip && ma != 0ull) {
                 if (is_aab) {
                     R t;
-                    if (aabox_t(tv.u0, tv.u1, tv.o, tv.inv, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx; }
+                    if (aabox_t(tv.u0, tv.u1, tv.o, tv.inv, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; }
                     trav_goto(mem, tv, tv.i + 2 * Pos<R>::unit);
                 }
             }
@@ -1396,9 +1393,9 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         return x;
                     };
                     R t;
-                    if (medium_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], tv.u1.w[0], ldi(tv.u1.w[2]), tv.hdr >> 4, tv.o, tv.d,
+                    if (medium_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], tv.u1.w[0], ldi(tv.u1.w[2]), hdr_payload(tv.hdr), tv.o, tv.d,
                                  tmin, tv.best_t, mxi, t)) {
-                        tv.best_t = t; tv.best_off = tv.i; tv.best_ctx = tv.ctx;
+                        tv.best_t = t; tv.best_off = tv.i;
                     }
                     trav_goto(mem, tv, tv.i + 2 * Pos<R>::unit);
                 }
@@ -1462,7 +1459,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         ray.d = tv.d;
                     }
                     V3<R> L;
-                    scatter = shade_hit(mem, sc, cam, ray, tv.best_t, tv.best_off, tv.best_ctx, beta, L, h);
+                    scatter = shade_hit(mem, sc, cam, ray, tv.best_t, tv.best_off, beta, L, h);
                     if (!scatter) add_sample(L);
                 }
                 // ---- 2
@@ -1650,7 +1647,7 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(SceneT<R> sc_arg, const rt
         o.normal[0] = o.normal[1] = o.normal[2] = 0;
         o.u = o.v = 0;
         if (tv.best_off >= 0) {
-            Hit<R> h = finalize(mem, sc, r, tv.best_t, tv.best_off, tv.best_ctx, true);
+            Hit<R> h = finalize(mem, sc, r, tv.best_t, tv.best_off, true);
             o.prim = h.prim;
             o.front_face = h.front ? 1 : 0;
             o.t = (double)h.t;

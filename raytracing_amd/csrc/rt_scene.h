@@ -95,7 +95,12 @@ RT_HD int32_t dec_int(double f) {
     __builtin_memcpy(&v, &f, 8);
     return (int32_t)v;
 }
-RT_HD int make_hdr(int kind, int payload) { return (payload << 4) | kind; }
+// record header: kind (4 bits) | kind-specific payload (8 bits: AABOX outward-normal mask, MEDIUM draw selector) | transform
+// context of the record (20 bits; a leaf's frame is a property of its place in the stream, so the traversal carries no
+// "current context" and no "context of the best hit": finalisation reads it here).  A BOX header is the integer 0.
+RT_HD int make_hdr(int kind, int payload, int ctx = 0) { return (int)(((unsigned)ctx << 12) | ((unsigned)(payload & 255) << 4) | (unsigned)kind); }
+RT_HD int hdr_payload(int h) { return (h >> 4) & 255; }
+RT_HD int hdr_ctx(int h) { return (int)((unsigned)h >> 12); }
 
 template <class R> struct alignas(16) XformT {
     int32_t kind;
