@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "../../include/rt_amd.h"
+#include <type_traits>
 #include "rt_scene.h"
 
 namespace rtamd {
@@ -841,6 +842,47 @@ template <class R> RT_DEV R perlin_turb(const PerlinT<R> &pn, V3<R> p, int depth
     return m_abs(accum);
 }
 
+// perlin_turb for ONE point by the whole wave (float kernels; all 64 lanes must be active).  A noise texture is rare on
+// screen -- final_scene's marble sphere covers a percent of the image -- so of the 45 lanes of a shading trip one or two
+// need it, and the 7 octaves x 8 lattice corners they would walk alone (900 instructions, run by 3 of 4 trips: 4 % of
+// the frame) are 56 independent terms: lane l evaluates corner (l & 7) of octave (l >> 3), a butterfly sum adds them.
+// The sum's order differs from perlin.h:38-47 (float rounding only; the double path keeps the serial loop).
+RT_DEV float perlin_turb_wave(const PerlinT<float> &pn, V3<float> p, int depth, int lane) {
+    float total = 0.0f;
+    const int a = (lane >> 2) & 1, b = (lane >> 1) & 1, d = lane & 1;
+    for (int base = 0; base < depth; base += 8) {
+        const int o = base + (lane >> 3);
+        const float up = __builtin_ldexpf(1.0f, o), weight = __builtin_ldexpf(1.0f, -o); // p * 2^o, 0.5^o: exact, as repeated doubling is
+        const V3<float> q = mk<float>(p.x * up, p.y * up, p.z * up);
+        const float fx = m_floor(q.x), fy = m_floor(q.y), fz = m_floor(q.z);
+        const float u = q.x - fx, v = q.y - fy, w = q.z - fz;
+        const int i = int(fx), j = int(fy), k = int(fz);
+        const float uu = u * u * (3.0f - 2.0f * u), vv = v * v * (3.0f - 2.0f * v), ww = w * w * (3.0f - 2.0f * w);
+        const int g = pn.perm_x[(i + a) & 255] ^ pn.perm_y[(j + b) & 255] ^ pn.perm_z[(k + d) & 255];
+        const V3<float> c = ld3(pn.randvec[g]);
+        const V3<float> wv = mk<float>(u - a, v - b, w - d);
+        const float term = (a ? uu : 1.0f - uu) * (b ? vv : 1.0f - vv) * (d ? ww : 1.0f - ww) * dot(c, wv);
+        if (o < depth) total += weight * term;
+    }
+    // sum over the wave: four DPP steps leave every lane of a row of 16 with its row's sum, four readlanes add the rows
+    auto dpp_add = [&](auto ctl) {
+        total += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, total), decltype(ctl)::value, 0xf, 0xf, false));
+    };
+    dpp_add(std::integral_constant<int, 0xb1>{});  // quad_perm [1,0,3,2]
+    dpp_add(std::integral_constant<int, 0x4e>{});  // quad_perm [2,3,0,1]
+    dpp_add(std::integral_constant<int, 0x124>{}); // row_ror:4
+    dpp_add(std::integral_constant<int, 0x128>{}); // row_ror:8
+    const int ti = __builtin_bit_cast(int, total);
+    const float sum = (__builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 16))) +
+                      (__builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 48)));
+    return m_abs(sum);
+}
+// texture.h:85 noise_texture::value given turb(p, 7)
+template <class R> RT_DEV V3<R> noise_color(const TexT<R> &t, V3<R> p, R turb) {
+    R s = R(1) + sin_wide(t.scale * p.z + R(10) * turb);
+    return mk<R>(R(.5) * s, R(.5) * s, R(.5) * s);
+}
+
 template <class R, class SC> RT_DEV V3<R> tex_value(const SC &sc, int tex, R u, R v, V3<R> p) {
     TexT<R> t = sc.tex(tex);
     for (int guard = 0; guard < 16 && t.kind == RT_TEX_CHECKER; guard++) { // texture.h:39
@@ -874,8 +916,7 @@ template <class R, class SC> RT_DEV V3<R> tex_value(const SC &sc, int tex, R u, 
     if (t.kind == RT_TEX_IMAGE) return mk<R>(R(.5), R(.5), R(.5));
 #endif
     if (t.kind == RT_TEX_NOISE) { // texture.h:85
-        R s = R(1) + sin_wide(t.scale * p.z + R(10) * perlin_turb(sc.perlin(t.a), p, 7));
-        return mk<R>(R(.5) * s, R(.5) * s, R(.5) * s);
+        return noise_color(t, p, perlin_turb(sc.perlin(t.a), p, 7));
     }
     return mk<R>(R(0), R(0), R(0));
 }
@@ -1086,7 +1127,9 @@ RT_DEV bool shade_hit(const Mem<R, ALL_LDS> &mem, const SC &sc, const CameraT<R>
 }
 
 // shade_scatter(): material::scatter and the mixture pdf for a hit that shade_hit() let through; the next ray and beta.
-template <class R, class SC> RT_DEV void shade_scatter(const SC &sc, RayT<R> &ray, const Hit<R> &h, V3<R> &beta, Rng<R> &g) {
+// has_turb: the material's texture is a noise_texture and `turb` its perlin turbulence at h.p (perlin_turb_wave()).
+template <class R, class SC>
+RT_DEV void shade_scatter(const SC &sc, RayT<R> &ray, const Hit<R> &h, V3<R> &beta, Rng<R> &g, bool has_turb, R turb) {
     const MatT<R> m = sc.mat(h.mat);
     if (m.kind == RT_MAT_METAL) { // material.h:66
         V3<R> reflected = reflect(ray.d, h.n);
@@ -1118,7 +1161,9 @@ template <class R, class SC> RT_DEV void shade_scatter(const SC &sc, RayT<R> &ra
     }
     // lambertian / isotropic: mixture of light sampling and BRDF sampling (camera.h:313-325, pdf.h:69-85)
     const bool lambert = (m.kind == RT_MAT_LAMBERTIAN);
-    V3<R> atten = tex_value(sc, m.tex, h.u, h.v, h.p);
+    V3<R> atten;
+    if (has_turb) atten = noise_color(sc.tex(m.tex), h.p, turb);
+    else atten = tex_value(sc, m.tex, h.u, h.v, h.p);
     V3<R> dir;
     int picked = -1;
     if (g.next() < R(0.5)) dir = light_random(sc, h.p, g, picked);
@@ -1193,6 +1238,9 @@ enum : int { RT_MAX_SCHED_CHUNKS = 24 };
 #endif
 #ifndef RT_BOX_REPEAT
 #define RT_BOX_REPEAT 24
+#endif
+#ifndef RT_WAVE_NOISE
+#define RT_WAVE_NOISE 1
 #endif
 #ifndef RT_BOX_REPEAT_MIN
 #define RT_BOX_REPEAT_MIN 8
@@ -1452,6 +1500,8 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                 };
                 // ---- 1
                 Hit<R> h;
+                h.p = mk<R>(R(0), R(0), R(0));
+                h.mat = 0;
                 bool scatter = false;
                 if (ready) {
                     if constexpr (sizeof(R) == 4) { // traversal ended in the world frame: tv holds the world-space ray
@@ -1539,6 +1589,31 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     }
                 }
                 // ---- 3
+                // (noise textures first, by the whole wave for one lane at a time: see perlin_turb_wave)
+                bool has_turb = false;
+                R turb = R(0);
+                if constexpr (sizeof(R) == 4 && RT_WAVE_NOISE) {
+                    int noise_idx = -1;
+                    if (scatter) {
+                        const MatT<R> m = sc.mat(h.mat);
+                        if (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_ISOTROPIC) {
+                            const TexT<R> t = sc.tex(m.tex);
+                            if (t.kind == RT_TEX_NOISE) noise_idx = t.a;
+                        }
+                    }
+                    unsigned long long mn = lane_mask(noise_idx >= 0);
+                    while (mn) { // wave-uniform
+                        const int src = __builtin_ctzll(mn);
+                        mn &= mn - 1;
+                        auto from = [&](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src)); };
+                        const V3<float> q = mk<float>(from((float)h.p.x), from((float)h.p.y), from((float)h.p.z));
+                        const float tw = perlin_turb_wave(sc.perlin(__builtin_amdgcn_readlane(noise_idx, src)), q, 7, lane);
+                        if (lane == src) {
+                            turb = tw;
+                            has_turb = true;
+                        }
+                    }
+                }
                 if (scatter || fresh) {
                     if (fresh) bounce = 0;
                     Rng<R> g;
@@ -1554,7 +1629,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         ray = get_ray(cam, fi, fj, si, sj, g);
                         beta = mk<R>(R(1), R(1), R(1));
                     } else {
-                        shade_scatter(sc, ray, h, beta, g);
+                        shade_scatter(sc, ray, h, beta, g, has_turb, turb);
                         bounce++;
                         if (bounce == cam.max_depth) { // depth exhausted: the recursion returns 0 here (camera.h:294-295)
                             add_sample(beta * mk<R>(R(0), R(0), R(0)));
