@@ -829,7 +829,7 @@ template <class R> class Flattener {
             if (best_axis >= 0) {
                 const int a = best_axis;
                 const double sc = NB / (chi[a] - clo[a]);
-                int *mid = std::partition(idx, idx + n, [&](int k) {
+                int *mid = std::stable_partition(idx, idx + n, [&](int k) { // stable: each side keeps the reference's relative order
                     const Leaf &l = lv[k];
                     int b = (int)((0.5 * (l.lo[a] + l.hi[a]) - clo[a]) * sc);
                     b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
@@ -847,10 +847,9 @@ template <class R> class Flattener {
                 const double cp = lv[p].lo[a] + lv[p].hi[a], cq = lv[q].lo[a] + lv[q].hi[a];
                 return cp < cq || (cp == cq && p < q);
             });
+            std::sort(idx, idx + n_left); // the leaves were collected in the reference's visiting order: keep it inside each side
+            std::sort(idx + n_left, idx + n);
         }
-        // keep the reference's relative order inside each side (the leaves were collected in its visiting order)
-        std::sort(idx, idx + n_left);
-        std::sort(idx + n_left, idx + n);
         // Which side goes first in the stream (the walk has no stack, so the order is the same for every ray).  0: as split
         // (low centroids), 1 / 2: larger / smaller box, 3 / 4: more / fewer leaves, 5: larger box area per leaf, 6: larger
         // area per tree level, 7 / 8: larger / smaller (share of the box its leaves cover) / (tree levels).
