@@ -411,6 +411,15 @@ int rt_init(int device, rt_ctx **out) {
         rt_shutdown(ctx);
         return RT_ERR_HIP;
     }
+    // ... and a copy of the size of a scene blob takes another path (pinned staging chunks, set up on its first use: 6 ms
+    // of the first upload, whatever its size).  The static scratch array is a destination that needs no allocation.
+    {
+        const std::vector<unsigned char> warm((size_t)2 << 20, 0);
+        if (hipMemcpy(ctx->static_scratch + RT_STATIC_COUNTER_BYTES, warm.data(), warm.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            rt_shutdown(ctx);
+            return RT_ERR_HIP;
+        }
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cus = prop.multiProcessorCount;
     if (const char *e1 = std::getenv("RT_AMD_LDS_UNITS")) ctx->lds_limit_units = std::atoi(e1);
