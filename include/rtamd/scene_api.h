@@ -31,6 +31,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../rt_amd.h"
@@ -974,26 +975,38 @@ inline void writePPMImage(const Image *image, const char *filename) {
     fprintf(fp, "P3\n");
     fprintf(fp, "%d %d\n", image->width, image->height);
     fprintf(fp, "255\n");
+    // 6.2 M integers at 1080p: formatted into memory by up to four threads (one band of pixels each), written in order
     const size_t n = (size_t)image->width * image->height;
-    std::vector<char> buf(n * 36 + 1); // an int takes at most 11 characters
-    char *o = buf.data();
-    auto put = [&](int v, char sep) {
-        if (v >= 0 && v < 1000) {
-            if (v >= 100) *o++ = char('0' + v / 100);
-            if (v >= 10) *o++ = char('0' + (v / 10) % 10);
-            *o++ = char('0' + v % 10);
-        } else {
-            o += snprintf(o, 12, "%d", v);
+    const int n_bands = n >= (size_t)1 << 18 ? 4 : 1;
+    std::vector<std::vector<char>> bands((size_t)n_bands);
+    auto format_band = [&](int b) {
+        const size_t k0 = n * (size_t)b / (size_t)n_bands, k1 = n * (size_t)(b + 1) / (size_t)n_bands;
+        std::vector<char> &buf = bands[(size_t)b];
+        buf.resize((k1 - k0) * 36 + 1); // an int takes at most 11 characters
+        char *o = buf.data();
+        auto put = [&](int v, char sep) {
+            if (v >= 0 && v < 1000) {
+                if (v >= 100) *o++ = char('0' + v / 100);
+                if (v >= 10) *o++ = char('0' + (v / 10) % 10);
+                *o++ = char('0' + v % 10);
+            } else {
+                o += snprintf(o, 12, "%d", v);
+            }
+            *o++ = sep;
+        };
+        for (size_t k = k0; k < k1; k++) {
+            const int *ptr = &image->data[3 * k];
+            put(ptr[0], ' ');
+            put(ptr[1], ' ');
+            put(ptr[2], '\n');
         }
-        *o++ = sep;
+        buf.resize((size_t)(o - buf.data()));
     };
-    for (size_t k = 0; k < n; k++) {
-        const int *ptr = &image->data[3 * k];
-        put(ptr[0], ' ');
-        put(ptr[1], ' ');
-        put(ptr[2], '\n');
-    }
-    fwrite(buf.data(), 1, (size_t)(o - buf.data()), fp);
+    std::vector<std::thread> workers;
+    for (int b = 1; b < n_bands; b++) workers.emplace_back(format_band, b);
+    format_band(0);
+    for (std::thread &t : workers) t.join();
+    for (const std::vector<char> &buf : bands) fwrite(buf.data(), 1, buf.size(), fp);
     fclose(fp);
 }
 
