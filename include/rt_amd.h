@@ -225,6 +225,13 @@ int rt_abi_sizeof(const char *name);
 /* Flatten + upload a scene: replaces the construction of the reference's in-memory graph
  * (cpuRenderer.cpp:86-401 build it; bvh_node ctor bvh.h:15-41 is run by the host API before this). */
 int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out);
+/* rt_scene_upload with the float stream's bounding-volume hierarchy built ON THE DEVICE (Morton keys, radix sort, a
+ * binary radix tree, boxes fitted bottom-up, the threaded stream written in place) instead of on the host: for scenes that
+ * are rebuilt per frame.  Replaces bvh_node's constructor (bvh.h:15-41: random axis, std::sort, median split; the
+ * reference's CUDA tree builds on the device as well, src/cuda/bvh.h:140-188) for the production (f32) path; closest hits
+ * do not depend on the hierarchy.  RT_ERR_UNSUPPORTED if a leaf of the scene is more than one record (an instance that
+ * cannot be emitted in world space, a constant_medium whose boundary is not a static sphere): use rt_scene_upload. */
+int rt_scene_upload_device_build(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out);
 void rt_scene_free(rt_scene *scene);
 /* out[4] = { threaded device nodes, lights, f32 device bytes, f64 device bytes (0 until a call first asks for
  * RT_PREC_F64: the parity stream is built lazily) }. */
@@ -244,6 +251,9 @@ int rt_scene_flatten_info(const rt_scene_desc *desc, int32_t *out);
  * record that starts at each unit (or -1) into `node_ids` (may be NULL); *n_units = size of the whole stream.
  * No reference counterpart. */
 int rt_scene_flatten_stream(const rt_scene_desc *desc, void *units, int32_t *node_ids, size_t cap_units, size_t *n_units);
+/* The same view of an UPLOADED scene's f32 stream, copied back from the device (the stream of
+ * rt_scene_upload_device_build exists nowhere else).  No reference counterpart. */
+int rt_scene_download_stream(const rt_scene *scene, void *units, int32_t *node_ids, size_t cap_units, size_t *n_units);
 
 /* Closest hit of each ray in [0.001, inf): replaces world.hit(r, interval(0.001, infinity), rec)
  * (camera.h:300 -> hittable_list.h:24 / bvh.h:43).  `xi` (optional, one per ray) is the uniform every

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/rt_amd.h"
+#include "rt_build.h"
 #include "rt_flatten.h"
 #include "rt_launch.h"
 #include "rt_scene.h"
@@ -131,15 +132,28 @@ double wall_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, DeviceScene<R> &ds) {
+// device_build (float stream only): the hierarchy is built on the device from the leaf records (rt_build.h)
+template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, DeviceScene<R> &ds, bool device_build = false) {
     const bool timing = std::getenv("RT_AMD_TIMING") != nullptr; // development aid: where an upload's time goes
     const double t0 = wall_ms();
     Flat<R> f;
     std::string err;
     // RT_AMD_REF_ORDER (development knob): the float stream keeps the reference's bvh_nodes and visiting order
     Flattener<R> fl(*desc, f, err, /*fuse_boxes=*/sizeof(R) == 4, /*own_hierarchy=*/sizeof(R) == 4 && !std::getenv("RT_AMD_REF_ORDER"));
-    int rc = fl.run();
+    std::vector<typename Flattener<R>::LeafRecord> leaves;
+    std::vector<UnitT<R>> leaf_units, leaf_cold;
+    double box_pad = 0;
+    int rc = device_build ? fl.run_leaves(leaves, box_pad) : fl.run();
     if (rc) return set_err(ctx, rc, err);
+    if (device_build) {
+        if (leaves.empty()) return set_err(ctx, RT_ERR_UNSUPPORTED, "device build: the world holds no primitive");
+        leaf_units.swap(f.stream);
+        leaf_cold.swap(f.cold);
+        const size_t total = built_stream_units(leaf_units.size(), leaves.size());
+        if (total > (size_t(1) << 25)) return set_err(ctx, RT_ERR_NOMEM, "flattened scene too large");
+        f.stream.assign(total, UnitT<R>{}); // the device writes these two ranges
+        f.cold.assign(total, UnitT<R>{});
+    }
     BlobBuilder b;
     size_t o_stream = b.add(f.stream), o_cold = b.add(f.cold);
     size_t o_bytes = b.add_bytes(desc->image_bytes, (size_t)desc->n_image_bytes);
@@ -157,6 +171,38 @@ template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, Device
         std::fprintf(stderr, "[rt_amd timing] upload<%s>: flatten + blob %.2f ms, hipMalloc %.2f ms, hipMemcpy of %zu bytes %.2f ms\n",
                      sizeof(R) == 4 ? "f32" : "f64", t1 - t0, t2 - t1, ds.bytes, wall_ms() - t2);
     uint8_t *base = (uint8_t *)ds.blob;
+    if constexpr (sizeof(R) == 4) {
+        if (device_build) {
+            const double t3 = wall_ms();
+            std::vector<BuildLeaf> bl(leaves.size());
+            float c_lo[3] = {INFINITY, INFINITY, INFINITY}, c_hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (size_t k = 0; k < leaves.size(); k++) {
+                bl[k].off = leaves[k].off;
+                bl[k].n = leaves[k].n;
+                for (int a = 0; a < 3; a++) {
+                    cvt_lo(leaves[k].lo[a], bl[k].lo[a]);
+                    cvt_hi(leaves[k].hi[a], bl[k].hi[a]);
+                    const float c = 0.5f * (bl[k].lo[a] + bl[k].hi[a]);
+                    if (std::isfinite(c)) {
+                        c_lo[a] = std::fmin(c_lo[a], c);
+                        c_hi[a] = std::fmax(c_hi[a], c);
+                    }
+                }
+            }
+            BlobBuilder in; // what the build reads: leaf table, leaf stream, its cold units
+            const size_t o_bl = in.add(bl), o_lu = in.add(leaf_units), o_lc = in.add(leaf_cold);
+            void *d_in = nullptr;
+            HIP_TRY(ctx, hipMalloc(&d_in, in.host.size()));
+            hipError_t e = hipMemcpy(d_in, in.host.data(), in.host.size(), hipMemcpyHostToDevice);
+            if (e == hipSuccess)
+                e = build_stream_on_device((const BuildLeaf *)((uint8_t *)d_in + o_bl), (int)bl.size(), (const UnitT<float> *)((uint8_t *)d_in + o_lu),
+                                           (const UnitT<float> *)((uint8_t *)d_in + o_lc), (int)leaf_units.size(), (UnitT<float> *)(base + o_stream),
+                                           (UnitT<float> *)(base + o_cold), c_lo, c_hi, (float)box_pad);
+            (void)hipFree(d_in);
+            HIP_TRY(ctx, e);
+            if (timing) std::fprintf(stderr, "[rt_amd timing] device build of %zu leaves: %.2f ms\n", bl.size(), wall_ms() - t3);
+        }
+    }
     SceneT<R> &s = ds.sc;
     s.stream = (const UnitT<R> *)(base + o_stream);
     s.cold = (const UnitT<R> *)(base + o_cold);
@@ -443,7 +489,7 @@ void rt_shutdown(rt_ctx *ctx) {
 
 const char *rt_last_error(const rt_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out) {
+static int scene_upload(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out, bool device_build) {
     if (!ctx || !desc || !out) return RT_ERR_INVALID;
     *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -451,7 +497,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out) {
     if (!s) return set_err(ctx, RT_ERR_NOMEM, "out of host memory");
     s->ctx = ctx;
     s->n_nodes_desc = desc->n_nodes;
-    int rc = upload_one<float>(ctx, desc, s->f32); // validates `desc` before anything reads through its pointers
+    int rc = upload_one<float>(ctx, desc, s->f32, device_build); // validates `desc` before anything reads through its pointers
     if (rc != RT_OK) {
         rt_scene_free(s);
         return rc;
@@ -460,6 +506,9 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out) {
     *out = s;
     return RT_OK;
 }
+
+int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out) { return scene_upload(ctx, desc, out, false); }
+int rt_scene_upload_device_build(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out) { return scene_upload(ctx, desc, out, true); }
 
 void rt_scene_free(rt_scene *scene) {
     if (!scene) return;
@@ -489,6 +538,23 @@ int rt_scene_flatten_stream(const rt_scene_desc *desc, void *units, int32_t *nod
     if (n) std::memcpy(units, f.stream.data(), n * sizeof(UnitT<float>));
     if (node_ids)
         for (size_t k = 0; k < n; k++) node_ids[k] = dec_int(f.cold[k].w[3]);
+    return RT_OK;
+}
+
+int rt_scene_download_stream(const rt_scene *scene, void *units, int32_t *node_ids, size_t cap_units, size_t *n_units) {
+    if (!scene || !n_units || (cap_units > 0 && !units)) return RT_ERR_INVALID;
+    rt_ctx *ctx = scene->ctx;
+    const size_t total = (size_t)scene->f32.sc.n_units;
+    *n_units = total;
+    const size_t n = std::min(cap_units, total);
+    if (n == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy(units, scene->f32.sc.stream, n * sizeof(UnitT<float>), hipMemcpyDeviceToHost));
+    if (node_ids) {
+        std::vector<UnitT<float>> cold(n);
+        HIP_TRY(ctx, hipMemcpy(cold.data(), scene->f32.sc.cold, n * sizeof(UnitT<float>), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < n; k++) node_ids[k] = dec_int(cold[k].w[3]);
+    }
     return RT_OK;
 }
 

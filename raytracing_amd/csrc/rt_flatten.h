@@ -101,6 +101,51 @@ template <class R> class Flattener {
         return emit_lights();
     }
 
+    // For the device build (rt_build.h): the leaf records alone -- what run() would put under its own hierarchy -- written one
+    // after the other into f.stream / f.cold (no BOX records, no sentinel), with each leaf's place and bounds.
+    // RT_ERR_UNSUPPORTED if a leaf is more than one record (an instance that cannot be baked, a constant_medium with a
+    // boundary other than a static sphere): such scenes take the host build.
+    struct LeafRecord {
+        int off, n;
+        double lo[3], hi[3];
+    };
+    int run_leaves(std::vector<LeafRecord> &leaves, double &box_pad) {
+        int rc = validate();
+        if (rc) return rc;
+        convert_tables();
+        double m = 0;
+        for (int a = 0; a < 6; a++) {
+            const double v = std::fabs(d_.nodes[d_.world_root].bbox[a]);
+            if (std::isfinite(v)) m = std::fmax(m, v);
+        }
+        box_pad_ = 32.0 * 5.9604644775390625e-08 * 2.0 * m; // as in run()
+        box_pad = box_pad_;
+        primary_ = primary_medium();
+        f_.xforms.push_back(XformT<R>{});
+        std::vector<Leaf> lv;
+        rc = collect(d_.world_root, 0, Rigid{}, false, 0, 0, lv);
+        if (rc) return rc;
+        for (const Leaf &l : lv) {
+            const rt_node &n = d_.nodes[l.id];
+            const bool simple = l.baked || n.kind == RT_NODE_SPHERE || n.kind == RT_NODE_QUAD || n.kind == RT_NODE_TRIANGLE ||
+                                n.kind == RT_NODE_LIST /* a fused box */ ||
+                                (n.kind == RT_NODE_MEDIUM && d_.nodes[n.a].kind == RT_NODE_SPHERE && d_.spheres[d_.nodes[n.a].a].dcenter[0] == 0 &&
+                                 d_.spheres[d_.nodes[n.a].a].dcenter[1] == 0 && d_.spheres[d_.nodes[n.a].a].dcenter[2] == 0);
+            if (!simple) return fail(RT_ERR_UNSUPPORTED, "device build: node " + std::to_string(l.id) + " is not a single record (instance or general medium)");
+            LeafRecord r;
+            r.off = (int)f_.stream.size();
+            rc = emit_leaf(l, 0, 0);
+            if (rc) return rc;
+            r.n = (int)f_.stream.size() - r.off;
+            for (int a = 0; a < 3; a++) {
+                r.lo[a] = l.lo[a];
+                r.hi[a] = l.hi[a];
+            }
+            leaves.push_back(r);
+        }
+        return emit_lights();
+    }
+
   private:
     const rt_scene_desc &d_;
     Flat<R> &f_;

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")  # RT_AMD_LIB: diagnostic builds
 
 EXPORTS = ["rt_abi_sizeof", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_upload", "rt_scene_free",
-           "rt_scene_info", "rt_scene_flatten_info", "rt_scene_flatten_stream", "rt_trace_batch", "rt_render_device", "rt_tonemap_device", "rt_render",
+           "rt_scene_upload_device_build", "rt_scene_download_stream", "rt_scene_info", "rt_scene_flatten_info", "rt_scene_flatten_stream", "rt_trace_batch", "rt_render_device", "rt_tonemap_device", "rt_render",
            "rt_render_multi", "rt_render_static"]
 
 _lib = None
@@ -54,6 +54,10 @@ def load() -> C.CDLL:
     L.rt_last_error.argtypes = [vp]
     L.rt_scene_upload.restype = C.c_int
     L.rt_scene_upload.argtypes = [vp, C.POINTER(abi.SceneDesc), C.POINTER(vp)]
+    L.rt_scene_upload_device_build.restype = C.c_int
+    L.rt_scene_upload_device_build.argtypes = [vp, C.POINTER(abi.SceneDesc), C.POINTER(vp)]
+    L.rt_scene_download_stream.restype = C.c_int
+    L.rt_scene_download_stream.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.rt_scene_free.restype = None
     L.rt_scene_free.argtypes = [vp]
     L.rt_scene_info.restype = C.c_int
@@ -136,19 +140,34 @@ class Context:
             msg = self.L.rt_last_error(self.h)
             raise RtError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")
 
-    def upload(self, scene: abi.Scene) -> "DeviceScene":
-        return DeviceScene(self, scene)
+    def upload(self, scene: abi.Scene, device_build: bool = False) -> "DeviceScene":
+        """device_build: the float stream's hierarchy is built on the GPU (rt_scene_upload_device_build)."""
+        return DeviceScene(self, scene, device_build)
 
 
 class DeviceScene:
-    def __init__(self, ctx: Context, scene: abi.Scene):
+    def __init__(self, ctx: Context, scene: abi.Scene, device_build: bool = False):
         self.ctx = ctx
         self.host = scene
         d = scene.desc()
         h = C.c_void_p()
-        rc = ctx.L.rt_scene_upload(ctx.h, C.byref(d), C.byref(h))
-        ctx.check(rc, "rt_scene_upload")
+        if device_build:
+            rc = ctx.L.rt_scene_upload_device_build(ctx.h, C.byref(d), C.byref(h))
+            ctx.check(rc, "rt_scene_upload_device_build")
+        else:
+            rc = ctx.L.rt_scene_upload(ctx.h, C.byref(d), C.byref(h))
+            ctx.check(rc, "rt_scene_upload")
         self.h = h
+
+    def download_stream(self):
+        """The f32 record stream as it stands on the device: (units (n, 4) uint32, node ids per unit)."""
+        n = C.c_size_t(0)
+        self.ctx.check(self.ctx.L.rt_scene_download_stream(self.h, None, None, 0, C.byref(n)), "rt_scene_download_stream")
+        units = np.zeros((n.value, 4), dtype=np.uint32)
+        ids = np.zeros(n.value, dtype=np.int32)
+        self.ctx.check(self.ctx.L.rt_scene_download_stream(self.h, units.ctypes.data, ids.ctypes.data, n.value, C.byref(n)),
+                       "rt_scene_download_stream")
+        return units, ids
 
     def info(self) -> dict:
         out = np.zeros(5, dtype=np.int32)

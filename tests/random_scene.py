@@ -50,7 +50,9 @@ class _Builder:
         return self.node(abi.RT_NODE_LIST, a, len(kids))
 
 
-def build(seed: int, n_spheres: int = 240) -> abi.Scene:
+def build(seed: int, n_spheres: int = 240, single_records: bool = False) -> abi.Scene:
+    """single_records: leave out what is more than one record in the float stream (the quad-bounded medium, the unbaked
+    instance): what the device build accepts."""
     rng = np.random.default_rng(seed)
     b = _Builder()
     top = []
@@ -78,13 +80,15 @@ def build(seed: int, n_spheres: int = 240) -> abi.Scene:
     # media: material 1 (isotropic); a sphere boundary that encloses the scene's core, and a boundary made of two quads
     top.append(b.node(abi.RT_NODE_MEDIUM, b.sphere((0, 0, 0), 60.0, mat=-1), 1, p=(-1.0 / 0.004, 0, 0, 0)))
     slab = b.list([b.quad((-20, 8, -20), (40, 0, 0), (0, 0, 40)), b.quad((-20, 14, -20), (40, 0, 0), (0, 0, 40))])
-    top.append(b.node(abi.RT_NODE_MEDIUM, slab, 1, p=(-1.0 / 0.05, 0, 0, 0)))
+    if not single_records:
+        top.append(b.node(abi.RT_NODE_MEDIUM, slab, 1, p=(-1.0 / 0.05, 0, 0, 0)))
     # instances
     th = math.radians(25.0)
     cluster = b.list([b.sphere(rng.normal(size=3) * 3, 0.4 + rng.random()) for _ in range(20)])
     top.append(b.node(abi.RT_NODE_TRANSLATE, b.node(abi.RT_NODE_ROTATE_Y, cluster, p=(math.sin(th), math.cos(th), 0, 0)), p=(25, 10, 5, 0)))
     walls = b.list([b.quad(rng.uniform(-4, 4, size=3), rng.normal(size=3) * 3, rng.normal(size=3) * 3) for _ in range(6)])
-    top.append(b.node(abi.RT_NODE_TRANSLATE, b.node(abi.RT_NODE_ROTATE_Y, walls, p=(math.sin(-th), math.cos(-th), 0, 0)), p=(-25, 6, 12, 0)))
+    if not single_records:
+        top.append(b.node(abi.RT_NODE_TRANSLATE, b.node(abi.RT_NODE_ROTATE_Y, walls, p=(math.sin(-th), math.cos(-th), 0, 0)), p=(-25, 6, 12, 0)))
     world = b.list(top)
     light = b.quad((-5, 70, -5), (10, 0, 0), (0, 0, 10), mat=2)
     arrays = {

@@ -1,0 +1,55 @@
+"""Structure checks of a float record stream (test infrastructure; layout: raytracing_amd/csrc/rt_scene.h)."""
+import numpy as np
+
+_UNITS = {0: 2, 1: 2, 2: 2, 3: 2, 4: 5, 5: 3, 6: 2, 7: 2, 8: 3, 9: 2, 15: 2}  # units per record kind (csrc/rt_scene.h)
+
+
+def records(units):
+    """[(unit offset, kind)] of every record of a stream, walked linearly (sub-streams behind the main sentinel included)."""
+    ui = units.view(np.int32)
+    out, i = [], 0
+    while i < len(units):
+        kind = int(ui[i + 1, 3]) & 15
+        assert kind in _UNITS, (i, kind)
+        out.append((i, kind))
+        i += _UNITS[kind]
+    assert i == len(units)
+    return out
+
+
+
+def check(units, ids, r_units, r_ids):
+    """`units` against a reference stream of the same scene (`r_units`: e.g. the one in the reference's order): the same
+    leaf records (every primitive once; a medium below a span-1 bvh_node twice), every skip link forward, on a record
+    boundary and nested within the enclosing BOX's, every BOX inside the BOX that encloses it.  Returns the number of BOX
+    records."""
+    recs, r_recs = records(units), records(r_units)
+    leaves = sorted((int(ids[i]), k) for i, k in recs if k not in (0, 15, 6, 7))
+    r_leaves = sorted((int(r_ids[i]), k) for i, k in r_recs if k not in (0, 15, 6, 7))
+    assert leaves == r_leaves and len(leaves) > 0
+    assert sum(k == 6 for _, k in recs) == sum(k == 7 for _, k in recs)  # XF_ENTER / XF_EXIT pairs
+    starts = {i for i, _ in recs}
+    uf, ui = units.view(np.float32), units.view(np.int32)
+    open_boxes = []  # (end unit, bounds)
+    n_box = 0
+    for i, k in recs:
+        while open_boxes and open_boxes[-1][0] <= i:
+            open_boxes.pop()
+        if k == 15:
+            assert not open_boxes, "a sentinel inside a BOX's span"
+        if k in (6, 7):
+            open_boxes = [(e, None) for e, _ in open_boxes]  # bounds below an instance are in another frame
+        if k != 0:
+            continue
+        n_box += 1
+        link = int(ui[i + 1, 2])
+        assert link % 16 == 0 and link // 16 > i + 2 and link // 16 in starts, (i, link)
+        b = np.array([uf[i, 0], uf[i, 1], uf[i, 2], uf[i, 3], uf[i + 1, 0], uf[i + 1, 1]])
+        assert (b[0::2] <= b[1::2]).all()
+        if open_boxes:
+            end, outer = open_boxes[-1]
+            assert link // 16 <= end
+            if outer is not None:
+                assert (b[0::2] >= outer[0::2]).all() and (b[1::2] <= outer[1::2]).all(), (i, b, outer)
+        open_boxes.append((link // 16, b))
+    return n_box

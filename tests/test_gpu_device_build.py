@@ -1,0 +1,96 @@
+"""GPU (-m gpu): the float stream's hierarchy built on the device (rt_scene_upload_device_build, SURVEY 8f rank 3:
+Morton keys, radix sort, binary radix tree, bottom-up boxes, threaded stream written in place).  world.hit() is the closest
+hit over all primitives, so a device-built stream must (a) be a well-formed stream over exactly the host stream's leaves,
+(b) name the reference's primitives on the fixture rays -- the same bar as the host-built stream: ties and grazing rays
+explained, 0 unexplained --, (c) render the frame the host-built stream renders."""
+import time
+
+import numpy as np
+import pytest
+
+from raytracing_amd import abi, lib
+from tests import f32_bounds as fb
+from tests import fixtures as fx
+from tests import oracle_lib as O
+from tests import random_scene, stream_check
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(n):
+    return random_scene.build(int(n.split()[1]), single_records=True) if isinstance(n, str) else fx.scene(n)
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, "random 1", "random 2"])
+def test_device_built_stream_structure_and_hits(gpu_ctx, n):
+    sc = _scene(n)
+    t0 = time.perf_counter()
+    ds = gpu_ctx.upload(sc, device_build=True)
+    t_build = time.perf_counter() - t0
+    host = gpu_ctx.upload(sc)
+    try:
+        units, ids = ds.download_stream()
+        h_units, h_ids = lib.flatten_stream(sc)
+        n_box = stream_check.check(units, ids, h_units, h_ids)
+        n_leaves = sum(k not in (0, 15) for _, k in stream_check.records(units))
+        assert n_box == n_leaves - 1, "a binary tree over the leaves: one BOX record per internal node"
+        print(f"scene {n}: {n_leaves} leaves, {len(units)} units, upload with device build {t_build * 1e3:.1f} ms")
+        if isinstance(n, str):
+            rays = random_scene.rays(int(n.split()[1]))
+            xi = np.random.default_rng(5).random(len(rays))
+            want, _ = O.trace_batch(sc, rays, xi)
+        else:
+            rays, xi, want = fx.trace(n)
+        got = ds.trace_batch(rays, xi, abi.RT_PREC_F32)
+        rows = fb.classify(sc, rays, want, got, xi)
+        unexplained = [r for r in rows if r["status"] == "unexplained"]
+        assert not unexplained, f"{len(unexplained)} unexplained primitive-id mismatches, e.g. {unexplained[:3]}"
+        same = sum(r["status"] == "same" or bool(r.get("same_surface")) for r in rows)
+        assert same >= 0.97 * len(rows), (same, len(rows))
+        # the frame: same random streams, same closest hits -> the host-built stream's frame except where a tie or a
+        # grazing ray falls the other way
+        if isinstance(n, str):
+            from raytracing_amd.camera import make_camera
+            cam = make_camera(48, 27, 9, 8, 50.0, (90, 40, 120), (0, 5, 0), background=(0.6, 0.7, 0.9))
+        else:
+            cam, _, _, _ = fx.img(n)
+            cam = fx.with_size(cam, sqrt_spp=3, max_depth=8)
+        a_dev, _, st_dev = ds.render(cam, seed=21, precision=abi.RT_PREC_F32)
+        a_host, _, st_host = host.render(cam, seed=21, precision=abi.RT_PREC_F32)
+        assert abs(st_dev["rays"] - st_host["rays"]) <= 0.01 * st_host["rays"]
+        rel = np.abs(a_dev.astype(np.float64) - a_host) / np.maximum(np.abs(a_host), 1e-3)
+        ok = np.isfinite(rel)
+        assert np.mean(rel[ok] < 1e-4) >= 0.95, float(np.mean(rel[ok] < 1e-4))
+    finally:
+        ds.close()
+        host.close()
+
+
+@pytest.mark.parametrize("n", [2, 6])
+def test_device_build_refuses_multi_record_leaves(gpu_ctx, n):
+    """cornell's rotated box (an instance that stays an instance) and cornell_smoke's box-bounded media are more than one
+    record per leaf: the device build says so (the caller uses rt_scene_upload)."""
+    with pytest.raises(lib.RtError):
+        gpu_ctx.upload(fx.scene(n), device_build=True)
+
+
+def test_device_build_single_primitive_and_double_path(gpu_ctx):
+    """one leaf: no tree at all; and the double (parity) stream of a device-built scene is still the reference's order"""
+    sc = random_scene.build(3, n_spheres=0, single_records=True)
+    keep = [k for k in range(int(sc.nodes[sc.world_root]["b"]))][:1]
+    sc.nodes["b"][sc.world_root] = len(keep)
+    ds = gpu_ctx.upload(sc, device_build=True)
+    try:
+        units, _ = ds.download_stream()
+        kinds = [k for _, k in stream_check.records(units)]
+        assert kinds.count(0) == 0 and kinds[-1] == 15 and len(kinds) == 2
+    finally:
+        ds.close()
+    sc = fx.scene(3)
+    ds = gpu_ctx.upload(sc, device_build=True)
+    try:
+        rays, xi, want = fx.trace(3)
+        got = ds.trace_batch(rays, xi, abi.RT_PREC_F64)
+        assert (got["prim"] == want["prim"]).all()
+    finally:
+        ds.close()

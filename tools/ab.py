@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.getcwd())
 from raytracing_amd import abi, lib, scenes
 scene = scenes.build("final_scene", 1920, 1080, 1000, 50)
-ctx = lib.Context(0); ds = ctx.upload(scene)
+ctx = lib.Context(0); ds = ctx.upload(scene, device_build=bool(os.environ.get("DEVICE_BUILD")))  # DEVICE_BUILD=1: hierarchy built on the GPU
 best = 1e9
 for rep in range(2):
     _, _, st = ds.render(scene.camera, seed=1, s_begin=0, s_end=int(os.environ.get("S_END", "-1")), precision=abi.RT_PREC_F32, want_rgb8=False)
