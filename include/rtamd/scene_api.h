@@ -1088,6 +1088,7 @@ class camera {
     bool use_bvh = true;
     // extensions (not in the reference): RNG seed, and statistics of the last render
     uint64_t seed = 1984;
+    bool device_build = false; // see upload()
     rt_stats last_stats{};
     rtamd::FrameTiming last_timing{};
     bool write_file = true;
@@ -1221,7 +1222,11 @@ class camera {
         const double t1 = rtamd::now_ms();
         for (rt_ctx *ctx : rtamd::sessions()) {
             rt_scene *scene = nullptr;
-            int rc = rt_scene_upload(ctx, &d, &scene);
+            // device_build (extension field; $RTAMD_DEVICE_BUILD sets it too): the hierarchy of the production stream is built
+            // on the GPU -- for scenes that are rebuilt per frame; scenes it does not take fall back to the host build
+            int rc = RT_ERR_UNSUPPORTED;
+            if (device_build || getenv("RTAMD_DEVICE_BUILD")) rc = rt_scene_upload_device_build(ctx, &d, &scene);
+            if (rc == RT_ERR_UNSUPPORTED) rc = rt_scene_upload(ctx, &d, &scene);
             if (rc != RT_OK) throw std::runtime_error(std::string("rtamd: rt_scene_upload: ") + rt_last_error(ctx));
             up.scenes.push_back(scene);
         }

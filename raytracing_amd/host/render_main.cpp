@@ -57,6 +57,7 @@ int main(int argc_, char *argv_[]) {
                 rtamd::BuiltScene s;
                 if (!rtamd::build_scene(5, use_bvh, frame, asset_dir, s)) return 2;
                 setup(s);
+                s.cam.device_build = true; // a scene that is rebuilt for every frame: its hierarchy is built on the GPU
                 s.cam.render(s.world, s.lights);
             }
         } else {
