@@ -893,6 +893,7 @@ template <class R, class SC> RT_DEV V3<R> tex_value(const SC &sc, int tex, R u, 
         t = sc.tex(even ? t.a : t.b);
     }
     if (t.kind == RT_TEX_SOLID) return ld3(t.color); // texture.h:22
+    // (-DRT_EXP_NO_IMAGE / -DRT_EXP_NO_NOISE: measurement builds that stub a texture kind out -- what does it cost?)
 #ifndef RT_EXP_NO_IMAGE
     if (t.kind == RT_TEX_IMAGE) {                    // texture.h:60
         if (t.a < 0) return mk<R>(R(0), R(1), R(1));
@@ -1257,11 +1258,12 @@ struct RenderArgs {
 enum : int { A_BOX = 0, A_LEAF = 1, A_SHADE = 5, A_COUNT = 6, A_DEAL = 7 };
 
 // Persistent megakernel.  A workgroup stages the scene stream into LDS once, then each of its waves pulls work items
-// (8x2 pixel tile x chunk of the stratified sample range) from a global cursor and deals the item's (pixel, sample)
-// units to whichever lanes are free.  The wave is a state machine: at any time a lane is at a BOX / SPHERE / AABOX /
-// MEDIUM / other record, waiting to be shaded, or idle; each trip of the loop runs ONE code block, chosen
-// wave-uniformly, so the hot BOX step is never serialised behind leaf or shading code that only a few lanes need
-// (64-lane divergence is the limiter of this workload: see DESIGN.md, profiles/).
+// (8 x RT_TILE_H pixel tile x chunk of the stratified sample range) from a global cursor and deals the item's (pixel,
+// sample) units to whichever lanes are free.  The wave is a state machine: at any time a lane stands at a BOX record,
+// at a leaf record (sphere / AABOX / medium / one of the rarer kinds), waits to be shaded, or is idle; each trip of the
+// loop runs ONE of three blocks -- BOX steps, one step of every leaf kind that has lanes, or shading + dealing --
+// chosen wave-uniformly, so the hot BOX step is never serialised behind leaf or shading code that only a few lanes
+// need (64-lane divergence is the limiter of this workload: see DESIGN.md, profiles/).
 // per-wave item state (LdsLayout::state_ints ints behind the wave's accumulators):
 // slot k: ws[4k .. 4k+3] = tile origin i0, j0, chunk, valid; then the dealing item's slot, first sample and unit count
 enum : int { WS_SLOT_I0 = 0, WS_SLOT_J0 = 1, WS_SLOT_CHUNK = 2, WS_SLOT_VALID = 3, WS_CUR_SLOT = 4 * RT_ITEM_SLOTS, WS_CUR_S0 = 4 * RT_ITEM_SLOTS + 1,
@@ -1304,14 +1306,13 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     unsigned long long prof_idle = 0, prof_ready = 0, prof_all = 0, prof_tail = 0;
     unsigned long long sub_cyc[A_COUNT] = {}, sub_trips[A_COUNT] = {}, sub_lanes[A_COUNT] = {};
 #endif
-    // Work: an item = (8 x 2 pixel tile, chunk of the sample range) = 16 x samples UNITS, unit u = sample s0 + u / 16 of the
-    // tile's pixel u % 16.  Lanes do not own pixels: a lane whose path has ended takes the next unit (wave-level dealing:
+    // Work: an item = (8 x RT_TILE_H pixel tile, chunk of the sample range) = TPX x samples UNITS, unit u = sample s0 + u / TPX
+    // of the tile's pixel u % TPX.  Lanes do not own pixels: a lane whose path has ended takes the next unit (wave-level dealing:
     // rank among the asking lanes + the wave's cursor), so a pixel with short paths never leaves its lane idle while a
     // neighbour grinds through long ones; when the item has no units left the wave fetches the next item and keeps
     // dealing while the old items' last paths finish (NS items in flight, one accumulator slot each).  The RNG is keyed
     // by (pixel, sample), so the paths do not depend on who traces what; a finished path is added to its item's
-    // per-pixel accumulator in LDS (ds_add: the order of the adds follows this wave's schedule, so float sums repeat
-    // from run to run only to rounding once a wave handles several items).
+    // per-pixel accumulator in LDS (float kernels: 64-bit fixed point, so the sums do not depend on the order of the adds).
     constexpr int NS = LdsLayout<R>::item_slots;
     constexpr int TPX = LdsLayout<R>::tile_px, TSH = LdsLayout<R>::tile_shift; // pixels per item, log2 of it
     for (int k = lane; k < LdsLayout<R>::wave_acc; k += 64) acc[k] = Cell(0);
