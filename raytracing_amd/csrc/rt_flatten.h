@@ -788,18 +788,25 @@ template <class R> class Flattener {
         return rc;
     }
 
-    // Measured on final_scene 1080p (ms / frame; the reference's own nodes and order: 850).  Children in split order 858,
-    // larger box first 814, fewer leaves first 799, larger box area PER LEAF first 792 (the side that is cheap to search
-    // and likely to be hit goes first: a hit found there culls the other side's boxes); with BOX records for all nodes
-    // below 0.8 (two leaves) / 0.95 (more) of the parent's area 763.  A node of two leaves boxed only below 0.4: 901.
+    // Measured (ms / frame; final_scene 1080p with the reference's own nodes and order: 850).  What decides is less the
+    // number of records a ray visits than WHICH hierarchy the surface-area heuristic happens to produce and in which order
+    // its children stand -- the rays that paths send are not the heuristic's uniform ones (three quarters start on a
+    // surface), and 64 lanes walking one stream in lockstep care about coherence.  final_scene over the bin count alone:
+    // 4 bins 951, 5 674, 6 708, 8 678, 10 684, 11 712, 12 651, 13 692, 14 711, 16 696, 20 813, 24 817, 32 761.  Child
+    // order at 16 bins: split order 858, larger box first 814, fewer leaves first 799, larger box area PER LEAF first 792
+    // (+ BOX thresholds 0.8 / 0.95: 763; a two-leaf node boxed only below 0.4: 901).  The defaults are the best setting
+    // over the reference's five configurations: 12 bins, larger box first -- final_scene 634 (696 at 16 bins / area per
+    // leaf), cornell_box 105 (125), mesh_scene 475 (482), first_scene 126 (122), bounce frame 86 (86).  (development knobs:
+    // RT_AMD_BVH_BINS / _ORDER / _T2 / _TN; tools/grid_bvh.sh)
     struct BuildKnobs {
         double thr2 = 0.8, thrn = 0.95; // a node of 2 / of more leaves gets a BOX record if its area is below this share of its parent's
-        int order = 5;                  // which child goes first: see build()
-        int bins = 16;
+        int order = 1;                  // which child goes first: see build()
+        int bins = 12;
         BuildKnobs() { // development knobs
             if (const char *e = std::getenv("RT_AMD_BVH_T2")) thr2 = std::atof(e);
             if (const char *e = std::getenv("RT_AMD_BVH_TN")) thrn = std::atof(e);
             if (const char *e = std::getenv("RT_AMD_BVH_ORDER")) order = std::atoi(e);
+            if (const char *e = std::getenv("RT_AMD_BVH_BINS")) bins = std::min(32, std::max(2, std::atoi(e)));
         }
     };
     BuildKnobs knobs_;
