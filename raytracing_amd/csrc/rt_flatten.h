@@ -802,10 +802,15 @@ template <class R> class Flattener {
         double thr2 = 0.8, thrn = 0.95; // a node of 2 / of more leaves gets a BOX record if its area is below this share of its parent's
         int order = 1;                  // which child goes first: see build()
         int bins = 12;
+        double axis_min = 0;            // only axes whose centroid extent is at least this share of the widest are split
+        double overlap = 0.1;           // weight of the area the two sides of a split share, in the split's cost (0 -> 0.1:
+                                        // final_scene 635 -> 623, cornell_box 105 -> 103, mesh_scene 477 -> 471; 1.0: 665)
         BuildKnobs() { // development knobs
             if (const char *e = std::getenv("RT_AMD_BVH_T2")) thr2 = std::atof(e);
             if (const char *e = std::getenv("RT_AMD_BVH_TN")) thrn = std::atof(e);
             if (const char *e = std::getenv("RT_AMD_BVH_ORDER")) order = std::atoi(e);
+            if (const char *e = std::getenv("RT_AMD_BVH_AXIS_MIN")) axis_min = std::atof(e);
+            if (const char *e = std::getenv("RT_AMD_BVH_OVERLAP")) overlap = std::atof(e);
             if (const char *e = std::getenv("RT_AMD_BVH_BINS")) bins = std::min(32, std::max(2, std::atoi(e)));
         }
     };
@@ -844,9 +849,13 @@ template <class R> class Flattener {
             const int NB = knobs_.bins;
             double best = INFINITY;
             int best_axis = -1, best_bin = -1;
+            double max_ext = 0;
+            for (int a = 0; a < 3; a++)
+                if (std::isfinite(chi[a] - clo[a])) max_ext = std::fmax(max_ext, chi[a] - clo[a]);
             for (int a = 0; a < 3; a++) {
                 const double ext = chi[a] - clo[a];
                 if (!(ext > 0) || !std::isfinite(ext)) continue;
+                if (ext < knobs_.axis_min * max_ext) continue; // (a split across a thin extent stacks the two sides on one footprint)
                 struct Bin { double lo[3], hi[3]; int n; } bin[32];
                 for (int b = 0; b < NB; b++) { b_empty(bin[b].lo, bin[b].hi); bin[b].n = 0; }
                 const double sc = NB / ext;
@@ -862,11 +871,13 @@ template <class R> class Flattener {
                 double l3[3], h3[3];
                 b_empty(l3, h3);
                 int cnt = 0;
+                double rlo[32][3], rhi[32][3];
                 for (int b = NB - 1; b > 0; b--) {
                     b_grow(l3, h3, bin[b].lo, bin[b].hi);
                     cnt += bin[b].n;
                     ra[b] = b_area(l3, h3);
                     rn[b] = cnt;
+                    for (int c = 0; c < 3; c++) { rlo[b][c] = l3[c]; rhi[b][c] = h3[c]; }
                 }
                 b_empty(l3, h3);
                 cnt = 0;
@@ -874,7 +885,17 @@ template <class R> class Flattener {
                     b_grow(l3, h3, bin[b].lo, bin[b].hi);
                     cnt += bin[b].n;
                     if (cnt == 0 || rn[b + 1] == 0) continue;
-                    const double cost = b_area(l3, h3) * cnt + ra[b + 1] * rn[b + 1];
+                    double cost = b_area(l3, h3) * cnt + ra[b + 1] * rn[b + 1];
+                    if (knobs_.overlap > 0) { // a ray through the part the two sides share walks both
+                        double ol[3], oh[3];
+                        bool any = true;
+                        for (int c = 0; c < 3; c++) {
+                            ol[c] = std::fmax(l3[c], rlo[b + 1][c]);
+                            oh[c] = std::fmin(h3[c], rhi[b + 1][c]);
+                            any = any && oh[c] >= ol[c];
+                        }
+                        if (any) cost += knobs_.overlap * b_area(ol, oh) * (double)(cnt + rn[b + 1]);
+                    }
                     if (cost < best) { best = cost; best_axis = a; best_bin = b; }
                 }
             }
