@@ -1243,6 +1243,14 @@ enum : int { RT_MAX_SCHED_CHUNKS = 24 };
 #ifndef RT_WAVE_NOISE
 #define RT_WAVE_NOISE 1
 #endif
+// rounds of the leaf trip (the leaves of a node stand next to each other in the stream), lanes that must stand at a leaf
+// again for another round.  1 round: 600 ms; 2 rounds / 8 lanes: 592; 2 / 16: 598; 2 / 24: 604; 3 / 8: 589; 4 / 12: 593.
+#ifndef RT_LEAF_ROUNDS
+#define RT_LEAF_ROUNDS 2
+#endif
+#ifndef RT_LEAF_AGAIN_MIN
+#define RT_LEAF_AGAIN_MIN 8
+#endif
 #ifndef RT_BOX_REPEAT_MIN
 #define RT_BOX_REPEAT_MIN 8
 #endif
@@ -1407,62 +1415,83 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             // (Tried: d.d and its reciprocal kept with the ray instead of recomputed by every sphere and medium test -- two more
             // registers of loop-carried state, 711 -> 721 ms; spheres and sphere-bounded media sharing one solve of the
             // quadratic in one block -> 736 ms.  The short separate blocks below are what the scheduler handles best.)
-            // the leaf trip: one step of every kind that has lanes (a second step for lanes that meet the same kind again --
-            // the leaves of a BVH node are neighbours in the stream -- measured slower once the kinds share a trip)
-            if (leaf_trip && ms != 0ull) {
-                if (is_sph) {
-                    V3<R> cc = mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]);
-                    int next = tv.i + 2 * Pos<R>::unit;
-                    if (kind == K_MSPHERE) { // centre = c + time * d (sphere.h:30)
-                        const UnitT<R> u2 = mem.ld(next);
-                        cc = cc + scale<R>(ray.tm, mk<R>(u2.w[0], u2.w[1], u2.w[2]));
-                        next += Pos<R>::unit;
-                    } else if constexpr (sizeof(R) == 8) {
-                        cc = cc + scale<R>(ray.tm, mk<R>(R(0), R(0), R(0))); // the reference always evaluates center.at(time)
+            // the leaf trip: one step of every kind that has lanes, as ONE routine under `if (leaf_trip)` (four blocks each behind
+            // its own `if (leaf_trip && mask)`: 622 -> 600 ms for the same instructions -- the code the compiler lays round
+            // the loop's joins decides), run up to RT_LEAF_ROUNDS times per trip.  (A second step PER KIND for lanes that meet
+            // the same kind again measured slower.)
+            auto leaf_round = [&](const int kind, const bool is_sph, const bool is_aab, const bool is_med, const bool is_oth,
+                                  const unsigned long long ms, const unsigned long long ma, const unsigned long long mm,
+                                  const unsigned long long mo) {
+                if (leaf_trip && ms != 0ull) {
+                    if (is_sph) {
+                        V3<R> cc = mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]);
+                        int next = tv.i + 2 * Pos<R>::unit;
+                        if (kind == K_MSPHERE) { // centre = c + time * d (sphere.h:30)
+                            const UnitT<R> u2 = mem.ld(next);
+                            cc = cc + scale<R>(ray.tm, mk<R>(u2.w[0], u2.w[1], u2.w[2]));
+                            next += Pos<R>::unit;
+                        } else if constexpr (sizeof(R) == 8) {
+                            cc = cc + scale<R>(ray.tm, mk<R>(R(0), R(0), R(0))); // the reference always evaluates center.at(time)
+                        }
+                        R t;
+                        if (sphere_t(cc, tv.u0.w[3], tv.o, tv.d, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; }
+                        trav_goto(mem, tv, next);
                     }
-                    R t;
-                    if (sphere_t(cc, tv.u0.w[3], tv.o, tv.d, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; }
-                    trav_goto(mem, tv, next);
                 }
-            }
-            RT_SUB_BEGIN();
-            if (leaf_trip && ma != 0ull) {
-                if (is_aab) {
-                    R t;
-                    if (aabox_t(tv.u0, tv.u1, tv.o, tv.inv, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; }
-                    trav_goto(mem, tv, tv.i + 2 * Pos<R>::unit);
-                }
-            }
-            RT_SUB_END(2, ma);
-            if (leaf_trip && mm != 0ull) {
-                if (is_med) {
-                    auto mxi = [&](int node_id, int sel) {
-                        R x = med_xi;
-                        if (sel != 1) x = medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce, sel >> 1);
-                        return x;
-                    };
-                    R t;
-                    if (medium_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], tv.u1.w[0], ldi(tv.u1.w[2]), hdr_payload(tv.hdr), tv.o, tv.d,
-                                 tmin, tv.best_t, mxi, t)) {
-                        tv.best_t = t; tv.best_off = tv.i;
+                RT_SUB_BEGIN();
+                if (leaf_trip && ma != 0ull) {
+                    if (is_aab) {
+                        R t;
+                        if (aabox_t(tv.u0, tv.u1, tv.o, tv.inv, tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = tv.i; }
+                        trav_goto(mem, tv, tv.i + 2 * Pos<R>::unit);
                     }
-                    trav_goto(mem, tv, tv.i + 2 * Pos<R>::unit);
                 }
-            }
-            RT_SUB_END(3, mm);
-            // (letting these few lanes -- final_scene: the light's quad, 4 per trip on average -- wait until 8 / 16 of them
-            // stand here: 762 -> 782 / 794 ms; a waiting lane is a lost lane)
-            if (leaf_trip && mo != 0ull) {
-                if (is_oth) {
-                    auto mxi = [&](int node_id, int sel) {
-                        R x = med_xi;
-                        if (sel != 1) x = medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce, sel >> 1);
-                        return x;
-                    };
-                    trav_leaf_step<GEN_MEDIUM>(mem, sc, tv, ray, tmin, mxi);
+                RT_SUB_END(2, ma);
+                if (leaf_trip && mm != 0ull) {
+                    if (is_med) {
+                        auto mxi = [&](int node_id, int sel) {
+                            R x = med_xi;
+                            if (sel != 1) x = medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce, sel >> 1);
+                            return x;
+                        };
+                        R t;
+                        if (medium_t(mk<R>(tv.u0.w[0], tv.u0.w[1], tv.u0.w[2]), tv.u0.w[3], tv.u1.w[0], ldi(tv.u1.w[2]), hdr_payload(tv.hdr), tv.o, tv.d,
+                                     tmin, tv.best_t, mxi, t)) {
+                            tv.best_t = t; tv.best_off = tv.i;
+                        }
+                        trav_goto(mem, tv, tv.i + 2 * Pos<R>::unit);
+                    }
                 }
+                RT_SUB_END(3, mm);
+                // (letting these few lanes -- final_scene: the light's quad, 4 per trip on average -- wait until 8 / 16 of them
+                // stand here: 762 -> 782 / 794 ms; a waiting lane is a lost lane)
+                if (leaf_trip && mo != 0ull) {
+                    if (is_oth) {
+                        auto mxi = [&](int node_id, int sel) {
+                            R x = med_xi;
+                            if (sel != 1) x = medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce, sel >> 1);
+                            return x;
+                        };
+                        trav_leaf_step<GEN_MEDIUM>(mem, sc, tv, ray, tmin, mxi);
+                    }
+                }
+                RT_SUB_END(4, mo);
+            };
+            if (leaf_trip) {
+                leaf_round(kind, is_sph, is_aab, is_med, is_oth, ms, ma, mm, mo);
+#if RT_LEAF_ROUNDS > 1
+                // the leaves of a node stand next to each other in the stream: a second round, in the same trip, for the lanes
+                // that stand at a leaf again
+                for (int round = 1; round < RT_LEAF_ROUNDS; round++) {
+                    const int k2 = tv.hdr & 15;
+                    const bool s2 = k2 == K_SPHERE || k2 == K_MSPHERE, a2 = k2 == K_AABOX, m2 = k2 == K_MEDIUM;
+                    const bool o2 = k2 >= K_QUAD && k2 < K_IDLE && k2 != K_MSPHERE;
+                    const unsigned long long ms2 = lane_mask(s2), ma2 = lane_mask(a2), mm2 = lane_mask(m2), mo2 = lane_mask(o2);
+                    if (popc64(ms2 | ma2 | mm2 | mo2) < RT_LEAF_AGAIN_MIN) break;
+                    leaf_round(k2, s2, a2, m2, o2, ms2, ma2, mm2, mo2);
+                }
+#endif
             }
-            RT_SUB_END(4, mo);
             // The shading trip (and the trip that only deals, when nothing is in flight), in three steps:
             //   1. every lane whose traversal has finished gets its hit record; a path that ends here -- a miss, a light --
             //      needs no draw: its sample is added and the lane is free;
