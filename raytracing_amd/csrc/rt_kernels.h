@@ -1400,18 +1400,6 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             prof_all += 1;
             const int n_act = action == A_BOX ? popc64(mb) : action == A_LEAF ? popc64(ml) : nr;
 #endif
-            if (action == A_BOX) {
-                // a few BOX steps in a row while enough lanes stay at BOX records (amortises the block selection)
-                // (a BOX header is the integer 0: kind 0, no payload; one compare per step serves both the next step's lane
-                // mask and the repeat decision)
-                bool at_box = is_box;
-                for (int rep = 0; rep < RT_BOX_REPEAT; rep++) {
-                    if (at_box) trav_box_step(mem, tv, tmin);
-                    int h = tv.hdr;
-                    at_box = h == make_hdr(K_BOX, 0);
-                    if (popc64(lane_mask(at_box)) < RT_BOX_REPEAT_MIN) break;
-                }
-            }
             // (Tried: d.d and its reciprocal kept with the ray instead of recomputed by every sphere and medium test -- two more
             // registers of loop-carried state, 711 -> 721 ms; spheres and sphere-bounded media sharing one solve of the
             // quadratic in one block -> 736 ms.  The short separate blocks below are what the scheduler handles best.)
@@ -1477,6 +1465,19 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                 }
                 RT_SUB_END(4, mo);
             };
+            if (action == A_BOX) {
+                // a few BOX steps in a row while enough lanes stay at BOX records (amortises the block selection)
+                // (a BOX header is the integer 0: kind 0, no payload; one compare per step serves both the next step's lane
+                // mask and the repeat decision)
+                bool at_box = is_box;
+                for (int rep = 0; rep < RT_BOX_REPEAT; rep++) {
+                    if (at_box) trav_box_step(mem, tv, tmin);
+                    int h = tv.hdr;
+                    at_box = h == make_hdr(K_BOX, 0);
+                    if (popc64(lane_mask(at_box)) < RT_BOX_REPEAT_MIN) break;
+                }
+            }
+            // (the three blocks as an if / else-if chain instead of three ifs in a row: 591 -> 688 ms)
             if (leaf_trip) {
                 leaf_round(kind, is_sph, is_aab, is_med, is_oth, ms, ma, mm, mo);
 #if RT_LEAF_ROUNDS > 1
