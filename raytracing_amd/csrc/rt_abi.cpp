@@ -366,7 +366,11 @@ int enqueue_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, int
 
 void print_profile(rt_ctx *ctx, const unsigned long long *c) { // diagnostic builds (-DRT_PROFILE_*) fill counters[3..39]
     if (std::getenv("RT_AMD_PROFILE_ACTIONS")) {
+#if RT_QUEUES
+        const char *nm[6] = {"box", "leaf", "exchange", "nap", "-", "shade+deal"};
+#else
         const char *nm[6] = {"box", "leaf", "leaf/aabox", "leaf/medium", "leaf/other", "shade+deal"};
+#endif
         for (int k = 0; k < 6; k++)
             std::fprintf(stderr, "[rt_amd profile] %-11s cycles %.4g (%.1f%% of wave time) trips %.4g cyc/trip %.1f lanes/trip %.1f\n",
                          nm[k], (double)c[4 + 3 * k], 100.0 * (double)c[4 + 3 * k] / (double)(c[3] ? c[3] : 1), (double)c[5 + 3 * k],
@@ -375,6 +379,16 @@ void print_profile(rt_ctx *ctx, const unsigned long long *c) { // diagnostic bui
         std::fprintf(stderr, "[rt_amd profile] per trip: %.1f lanes idle (item tail), %.1f lanes waiting for shading, of 64; %.1f%% of trips after the item's last unit was dealt\n",
                      (double)c[33] / (double)(c[35] ? c[35] : 1), (double)c[34] / (double)(c[35] ? c[35] : 1), 100.0 * (double)c[36] / (double)(c[35] ? c[35] : 1));
     }
+#if RT_QUEUES
+    if (std::getenv("RT_AMD_PROFILE_ACTIONS"))
+        std::fprintf(stderr, "[rt_amd profile] rings, per trip: %.1f hits wait, %.1f rays wait, %.1f paths in the workgroup, %.1f room credits free\n",
+                     (double)c[22] / (double)(c[35] ? c[35] : 1), (double)c[23] / (double)(c[35] ? c[35] : 1),
+                     (double)c[24] / (double)(c[35] ? c[35] : 1), (double)c[25] / (double)(c[35] ? c[35] : 1));
+    if (std::getenv("RT_AMD_PROFILE_ACTIONS"))
+        std::fprintf(stderr, "[rt_amd profile] shading trip, cycles: take %.0f, hit records %.0f, deal %.0f, generate + scatter %.0f, put %.0f\n",
+                     (double)c[26] / (double)(c[20] ? c[20] : 1), (double)c[27] / (double)(c[20] ? c[20] : 1), (double)c[28] / (double)(c[20] ? c[20] : 1),
+                     (double)c[29] / (double)(c[20] ? c[20] : 1), (double)c[30] / (double)(c[20] ? c[20] : 1));
+#endif
     if (std::getenv("RT_AMD_PROFILE_TAIL")) { // builds with -DRT_PROFILE_TAIL: wave end times
         const double span = (double)(c[38] - c[37]), n_waves = (double)ctx->n_cus * 16.0;
         std::fprintf(stderr, "[rt_amd profile] waves busy on average %.1f%% of the kernel's span (first start to last end); wave run time min %.1f%% max %.1f%% of the span\n",
@@ -391,6 +405,8 @@ int collect_stats(rt_ctx *ctx, const RenderPlan &pl, const unsigned long long *c
     unsigned long long c[40];
     HIP_TRY(ctx, hipMemcpy(c, counters, sizeof(c), hipMemcpyDeviceToHost));
     if (pl.n_samples > 0) print_profile(ctx, c);
+    if (pl.n_samples > 0 && c[2] != 0) // (builds with RT_QUEUES: a wave gave up waiting on a ring -- a bug, not a property of the scene)
+        return set_err(ctx, RT_ERR_HIP, "render kernel: the ring protocol gave up (code " + std::to_string(c[2]) + ")");
     stats->samples = (uint64_t)pl.n_px * (uint64_t)pl.n_samples;
     stats->rays = pl.n_samples > 0 ? c[0] : 0;
     stats->kernel_ms = pl.n_samples > 0 ? ms : 0.0;

@@ -1766,5 +1766,9 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(SceneT<R> sc_arg, const rt
     }
 }
 
+#if RT_QUEUES
+#include "rt_kernel_q.h"
+#endif
+
 } // namespace rtamd
 #endif
