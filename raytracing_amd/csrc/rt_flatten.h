@@ -1102,6 +1102,35 @@ template <class R> class Flattener {
         case RT_NODE_QUAD: {
             const rt_quad &q = d_.quads[n.a];
             if (q.mat < 0) return fail(RT_ERR_INVALID, "world quad without material");
+            if (fuse_ && !std::getenv("RT_AMD_NO_FLAT_QUADS")) {
+                // An axis-aligned quad whose material never asks for rec.u / rec.v (walls, ceiling lights) is a box of no
+                // thickness: two units instead of five and the AABOX step instead of the general one.  The slab test accepts
+                // exactly the points of the plane inside the quad's edges, inclusive (quad.h:63-70: unit.contains); a ray
+                // IN the plane never hits (aabox_t: the slab's two distances are 0 or +-1e30 together; quad.h:38 rejects it
+                // too).  Both faces of the flat axis name this quad and carry its own normal.
+                int au = -1, av = -1;
+                bool aligned = true;
+                for (int a = 0; a < 3; a++) {
+                    if (q.u[a] != 0.0) { if (au >= 0) aligned = false; au = a; }
+                    if (q.v[a] != 0.0) { if (av >= 0) aligned = false; av = a; }
+                }
+                if (aligned && au >= 0 && av >= 0 && au != av && !tex_needs_uv(d_.materials[q.mat].tex)) {
+                    const int c = 3 - au - av;
+                    double lo[3], hi[3];
+                    for (int a = 0; a < 3; a++) {
+                        lo[a] = std::fmin(q.Q[a], q.Q[a] + q.u[a] + q.v[a]);
+                        hi[a] = std::fmax(q.Q[a], q.Q[a] + q.u[a] + q.v[a]);
+                    }
+                    lo[c] = hi[c] = q.Q[c];
+                    const int outward = q.normal[c] < 0 ? (1 << (2 * c)) : (1 << (2 * c + 1)); // which of the two faces' outward directions is the quad's normal
+                    const int off = push_units(2, id);
+                    f_.stream[off] = UnitT<R>{{F(lo[0]), F(hi[0]), F(lo[1]), F(hi[1])}};
+                    f_.stream[off + 1] = UnitT<R>{{F(lo[2]), F(hi[2]), I(q.mat), I(make_hdr(K_AABOX, outward, ctx))}};
+                    f_.cold[off] = UnitT<R>{{I(id), I(id), I(id), I(id)}};
+                    f_.cold[off + 1] = UnitT<R>{{I(id), I(id), I(0), I(0)}};
+                    return RT_OK;
+                }
+            }
             const int off = push_units(5, id);
             f_.stream[off] = UnitT<R>{{F(q.normal[0]), F(q.normal[1]), F(q.normal[2]), F(q.D)}};
             f_.stream[off + 1] = UnitT<R>{{F(q.Q[0]), F(q.Q[1]), F(q.Q[2]), I(make_hdr(K_QUAD, 0, ctx))}};

@@ -746,6 +746,10 @@ RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SC &sc, const RayT<R> &
         probe(u0.w[3], r.o.y, inv.y, 3);
         probe(u1.w[0], r.o.z, inv.z, 4);
         probe(u1.w[1], r.o.z, inv.z, 5);
+        // a box of no thickness is an axis-aligned quad (rt_flatten.h): its face is the flat axis', whatever edge the hit lies on
+        if (u0.w[0] == u0.w[1]) face = 0;
+        if (u0.w[2] == u0.w[3]) face = 2;
+        if (u1.w[0] == u1.w[1]) face = 4;
         const int axis = face >> 1;
         const R sgn = (face & 1) ? R(1) : R(-1); // outward direction of this face
         V3<R> outward = mk<R>(axis == 0 ? sgn : R(0), axis == 1 ? sgn : R(0), axis == 2 ? sgn : R(0));

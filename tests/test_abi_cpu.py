@@ -112,7 +112,8 @@ def test_flattener_stream_sizes_and_box_fusion(monkeypatch):
     monkeypatch.setenv("RT_AMD_REF_ORDER", "1")
     ref = {n: lib.flatten_info(fx.scene(n)) for n in (1, 3)}
     monkeypatch.delenv("RT_AMD_REF_ORDER")
-    assert ref[3]["f64_units"] - ref[3]["f32_units"] == 400 * (6 * 5 - 2) + 4 * 2
+    # (+ 3: the ceiling light, an axis-aligned quad, is a flat 2-unit AABOX record in the f32 stream)
+    assert ref[3]["f64_units"] - ref[3]["f32_units"] == 400 * (6 * 5 - 2) + 4 * 2 + 3
     assert ref[1]["f32_units"] == ref[1]["f64_units"]
     assert [info[n]["lights"] for n in (1, 2, 3, 4)] == [1, 2, 1, 2]
     # a box with one face moved is not fused
