@@ -107,7 +107,9 @@ def profiled_hbm_traffic():
     on gfx950 as MI355X_MICROARCH.md prescribes).  None when no summary is committed."""
     import ast
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_counters.txt")), reverse=True):
+    paths = glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_counters.txt"))
+    # the latest round's "final" set first, then the other sets, latest round first
+    for path in sorted(paths, key=lambda p: (os.path.basename(p)[:3], "_final_" in os.path.basename(p), os.path.basename(p)), reverse=True):
         try:
             for line in open(path):
                 if "render_kernel" in line:
