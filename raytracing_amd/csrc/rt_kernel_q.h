@@ -13,10 +13,14 @@
 // Rings: RT_QCAP entries of LdsLayout::q_fields dwords, field-major (a wave's accesses are conflict-free); four control
 // words each -- tail reserved / tail published / head reserved / head released.  A producer reserves entries with a
 // compare-and-swap on `tail reserved`, fills them and publishes IN ORDER (it waits until the publications before its own
-// are in: they are a few LDS stores away); a consumer does the same on the head pair.  Nothing ever waits for SPACE or
-// for ENTRIES: a wave that finds the hit ring full keeps its finished rays on their lanes, and a shading trip first takes
-// 64 "room" credits for the ray ring (returned for the rays it does not produce, and by whoever takes rays out).
-// The number of paths in the workgroup is bounded (RT_Q_POP_MAX), which bounds what the rings must hold.
+// are in: they are a few LDS stores away); a consumer does the same on the head pair.  Nothing waits for ENTRIES, and a
+// wave that finds the hit ring full keeps its finished rays on their lanes.  Only a shading trip waits, for SPACE in the
+// ray ring, and that wait ends: at most RT_Q_SHADERS waves shade at a time, the others take rays out whenever they have
+// idle lanes, and the number of paths in the workgroup is bounded (RT_Q_POP_MAX) below what both rings, full, plus every
+// other wave's lanes, all holding finished rays, would be (static_assert in the kernel).
+//
+// MEASURED SLOWER than render_kernel (116 vs 67 ms for 100 strata of final_scene, frames identical
+// bit for bit) and therefore not in the shipped library: what a waiting lane cost is now what an exchange trip costs.
 #ifndef RT_KERNEL_Q_H
 #define RT_KERNEL_Q_H
 
@@ -33,7 +37,7 @@
 #define RT_Q_SHADE_MIN 64
 #endif
 
-enum : int { QC_T_RES = 0, QC_T_DONE = 1, QC_H_RES = 2, QC_H_DONE = 3, QC_HIT = 0, QC_RAY = 4, QC_ROOM = 8, QC_POP = 9, QC_PANIC = 10 };
+enum : int { QC_T_RES = 0, QC_T_DONE = 1, QC_H_RES = 2, QC_H_DONE = 3, QC_HIT = 0, QC_RAY = 4, QC_ROOM = 8 /* waves in a shading trip */, QC_POP = 9, QC_PANIC = 10 };
 enum : int { A_XCHG = 2, A_NONE = 3 };
 
 RT_DEV unsigned q_ld(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
