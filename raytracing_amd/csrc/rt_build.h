@@ -25,10 +25,11 @@ inline size_t built_stream_units(size_t leaf_units, size_t n_leaves) { return le
 
 // d_leaves / d_leaf_units / d_leaf_cold: device copies of the leaf table and the leaf stream (+ its cold units).
 // d_stream / d_cold: built_stream_units() units each.  c_lo / c_hi: bounds of the leaves' centroids (for the Morton grid).
-// box_pad: see Flattener::run (flat float boxes).  Synchronous: returns after the stream is complete.
+// box_pad: see Flattener::run (flat float boxes).  link_base: units in front of d_stream[0] in the scene's stream (leaves the
+// host put ahead of the tree): skip links are positions in the whole stream.  Synchronous: returns after the stream is complete.
 hipError_t build_stream_on_device(const BuildLeaf *d_leaves, int n_leaves, const UnitT<float> *d_leaf_units, const UnitT<float> *d_leaf_cold,
                                   int leaf_units, UnitT<float> *d_stream, UnitT<float> *d_cold, const float c_lo[3], const float c_hi[3],
-                                  float box_pad);
+                                  float box_pad, int link_base = 0);
 
 } // namespace rtamd
 #endif

@@ -127,7 +127,8 @@ __device__ inline int offset_of(const unsigned long long *k, const BuildLeaf *L,
 }
 
 __global__ void emit_kernel(const unsigned long long *k, const BuildLeaf *L, int n, Tree t, const UnitT<float> *leaf_units,
-                            const UnitT<float> *leaf_cold, UnitT<float> *stream, UnitT<float> *cold, int total_units, float box_pad) {
+                            const UnitT<float> *leaf_cold, UnitT<float> *stream, UnitT<float> *cold, int total_units, float box_pad,
+                            int link_base) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const UnitT<float> zero{{0.0f, 0.0f, 0.0f, 0.0f}};
     const UnitT<float> no_node{{0.0f, 0.0f, 0.0f, enc_int(-1, 0.0f)}};
@@ -148,7 +149,7 @@ __global__ void emit_kernel(const unsigned long long *k, const BuildLeaf *L, int
             hi[a] = t.hi[3 * i + a] + pad;
         }
         stream[o] = UnitT<float>{{lo[0], hi[0], lo[1], hi[1]}};
-        stream[o + 1] = UnitT<float>{{lo[2], hi[2], enc_int((o + t.size[i]) * (int)sizeof(UnitT<float>), 0.0f), enc_int(make_hdr(K_BOX, 0), 0.0f)}};
+        stream[o + 1] = UnitT<float>{{lo[2], hi[2], enc_int((link_base + o + t.size[i]) * (int)sizeof(UnitT<float>), 0.0f), enc_int(make_hdr(K_BOX, 0), 0.0f)}};
         cold[o] = no_node;
         cold[o + 1] = zero;
     } else if (g == 2 * n - 1) { // the sentinel
@@ -163,7 +164,7 @@ __global__ void emit_kernel(const unsigned long long *k, const BuildLeaf *L, int
 
 hipError_t build_stream_on_device(const BuildLeaf *d_leaves, int n, const UnitT<float> *d_leaf_units, const UnitT<float> *d_leaf_cold,
                                   int leaf_units, UnitT<float> *d_stream, UnitT<float> *d_cold, const float c_lo[3], const float c_hi[3],
-                                  float box_pad) {
+                                  float box_pad, int link_base) {
     if (n < 1) return hipErrorInvalidValue;
     const int total = (int)built_stream_units((size_t)leaf_units, (size_t)n);
     // one scratch allocation: keys in/out, the tree, the sort's own storage
@@ -198,7 +199,7 @@ hipError_t build_stream_on_device(const BuildLeaf *d_leaves, int n, const UnitT<
             tree_kernel<<<blocks, TPB, 0, 0>>>(k1, n, t);
             fit_kernel<<<blocks, TPB, 0, 0>>>(k1, d_leaves, n, t);
         }
-        emit_kernel<<<(2 * n + TPB - 1) / TPB, TPB, 0, 0>>>(k1, d_leaves, n, t, d_leaf_units, d_leaf_cold, d_stream, d_cold, total, box_pad);
+        emit_kernel<<<(2 * n + TPB - 1) / TPB, TPB, 0, 0>>>(k1, d_leaves, n, t, d_leaf_units, d_leaf_cold, d_stream, d_cold, total, box_pad, link_base);
         e = hipGetLastError();
         if (e != hipSuccess) break;
         e = hipStreamSynchronize(0);

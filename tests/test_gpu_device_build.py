@@ -33,7 +33,11 @@ def test_device_built_stream_structure_and_hits(gpu_ctx, n):
         h_units, h_ids = lib.flatten_stream(sc)
         n_box = stream_check.check(units, ids, h_units, h_ids)
         n_leaves = sum(k not in (0, 15) for _, k in stream_check.records(units))
-        assert n_box == n_leaves - 1, "a binary tree over the leaves: one BOX record per internal node"
+        # leaves that span most of the scene stand in front of the tree, unboxed (rt_abi.cpp); the rest: a binary tree
+        kinds = [k for _, k in stream_check.records(units)]
+        n_top = next((i for i, k in enumerate(kinds) if k == 0), n_leaves - 1)
+        assert n_top <= 8 and all(k not in (0, 15) for k in kinds[:n_top])
+        assert n_box == n_leaves - n_top - 1, "a binary tree over the other leaves: one BOX record per internal node"
         print(f"scene {n}: {n_leaves} leaves, {len(units)} units, upload with device build {t_build * 1e3:.1f} ms")
         if isinstance(n, str):
             rays = random_scene.rays(int(n.split()[1]))
