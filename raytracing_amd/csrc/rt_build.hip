@@ -2,6 +2,7 @@
 #include "rt_build.h"
 
 #include <hipcub/hipcub.hpp>
+#include <cstdlib>
 
 namespace rtamd {
 namespace {
@@ -77,7 +78,7 @@ __device__ inline float box_area(const float lo[3], const float hi[3]) {
 }
 
 // bottom-up: the second thread to arrive at a node finds both children complete and fits the node
-__global__ void fit_kernel(const unsigned long long *k, const BuildLeaf *L, int n, Tree t) {
+__global__ void fit_kernel(const unsigned long long *k, const BuildLeaf *L, int n, Tree t, int order) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     int node = t.parent_l[p];
@@ -107,7 +108,8 @@ __global__ void fit_kernel(const unsigned long long *k, const BuildLeaf *L, int 
         t.size[node] = 2 + size[0] + size[1];
         t.count[node] = count[0] + count[1];
         // the child with the larger box area per leaf goes first (rt_flatten.h, BuildKnobs)
-        t.first_is_right[node] = box_area(lo[1], hi[1]) * (float)count[0] > box_area(lo[0], hi[0]) * (float)count[1] ? 1 : 0;
+        const float a0 = box_area(lo[0], hi[0]), a1 = box_area(lo[1], hi[1]);
+        t.first_is_right[node] = order == 1 ? (a1 > a0 ? 1 : 0) : order == 3 ? (count[1] < count[0] ? 1 : 0) : (a1 * (float)count[0] > a0 * (float)count[1] ? 1 : 0);
         node = t.parent_i[node];
     }
 }
@@ -187,6 +189,8 @@ hipError_t build_stream_on_device(const BuildLeaf *d_leaves, int n, const UnitT<
     t.hi = t.lo + 3 * ni;
     auto scale = [&](int a) { const float ext = c_hi[a] - c_lo[a]; return ext > 0.0f && ext < 3.0e38f ? 1024.0f / ext : 0.0f; };
     const int blocks = (n + TPB - 1) / TPB;
+    int order = 5;
+    if (const char *e = getenv("RT_AMD_DEV_ORDER")) order = atoi(e); // development knob
     do {
         e = hipMemsetAsync(tmp + o_int, 0xff, up(4 * (7 * ni + (size_t)n)), 0); // parents = -1 ...
         if (e != hipSuccess) break;
@@ -197,7 +201,7 @@ hipError_t build_stream_on_device(const BuildLeaf *d_leaves, int n, const UnitT<
         if (e != hipSuccess) break;
         if (n > 1) {
             tree_kernel<<<blocks, TPB, 0, 0>>>(k1, n, t);
-            fit_kernel<<<blocks, TPB, 0, 0>>>(k1, d_leaves, n, t);
+            fit_kernel<<<blocks, TPB, 0, 0>>>(k1, d_leaves, n, t, order);
         }
         emit_kernel<<<(2 * n + TPB - 1) / TPB, TPB, 0, 0>>>(k1, d_leaves, n, t, d_leaf_units, d_leaf_cold, d_stream, d_cold, total, box_pad, link_base);
         e = hipGetLastError();
