@@ -1265,6 +1265,7 @@ struct RenderArgs {
     int32_t tiles_x, tiles_y;
     int32_t n_chunks;
     int32_t out_i64;         // float kernels: `out` receives 64-bit fixed-point cells (chunks summed afterwards), else floats
+    int32_t shade_t;         // lanes that must wait before the shading block runs (RT_SHADE_T unless the launcher knows better)
     int32_t chunk_start[RT_MAX_SCHED_CHUNKS + 1];        // decreasing-size schedule (chunk c = [chunk_start[c], chunk_start[c+1]))
 };
 enum : int { A_BOX = 0, A_LEAF = 1, A_SHADE = 5, A_COUNT = 6, A_DEAL = 7 };
@@ -1390,7 +1391,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             // (ONE leaf trip serves every lane that stands at a non-BOX record, each kind's code under its own mask: four
             // blocks with 14 - 35 lanes each cost four trips' worth of selection and loop-join overhead; merged: 903 -> 884 ms)
             const unsigned long long ml = ms | ma | mm | mo;
-            if (nr < RT_SHADE_T) {
+            if (nr < a.shade_t) {
                 const unsigned sb = ((unsigned)(popc64(mb) * RT_W_BOX) << 3) | A_BOX, sl = ((unsigned)(popc64(ml) * RT_W_LEAF) << 3) | A_LEAF;
                 const unsigned best = smax_u32(sb, sl);
                 if (best >= 8u) action = (int)(best & 7u);

@@ -1,6 +1,7 @@
 // rt_launch_impl.h -- shared body of the per-precision launcher translation units.
 #ifndef RT_LAUNCH_IMPL_H
 #define RT_LAUNCH_IMPL_H
+#include <cstdlib>
 #include "rt_kernels.h"
 #include "rt_launch.h"
 
@@ -24,6 +25,11 @@ hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const Rende
     a.chunk_size = rl.chunk_size;
     a.n_chunks = rl.n_chunks;
     a.out_i64 = sizeof(R) == 4 ? rl.out_i64 : 0;
+    // A stream of a few records (cornell_box: 14, no BOX among them) is walked by all lanes in step: the shading trips are
+    // what costs, and fuller ones pay (cornell_box 600 x 600 @1000: 83.6 ms at 40 waiting lanes, 79.2 at 52, 76.9 at 56,
+    // 76.8 at 60; every larger scene is slower above 44: first_scene 120 -> 154 at 56, final_scene 562 -> 657).
+    a.shade_t = sc.n_units <= 64 ? 56 : RT_SHADE_T;
+    if (const char *e = std::getenv("RT_AMD_SHADE_T")) a.shade_t = std::atoi(e); // development knob
     for (int k = 0; k <= RT_MAX_SCHED_CHUNKS; k++) a.chunk_start[k] = rl.chunk_start[k];
     if (rl.chunk_size == 0 && (rl.n_chunks < 1 || rl.n_chunks > RT_MAX_SCHED_CHUNKS)) return hipErrorInvalidValue;
     a.tiles_x = (cam.W + 7) / 8;
