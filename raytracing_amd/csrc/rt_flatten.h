@@ -128,7 +128,7 @@ template <class R> class Flattener {
         for (const Leaf &l : lv) {
             const rt_node &n = d_.nodes[l.id];
             const bool simple = l.baked || n.kind == RT_NODE_SPHERE || n.kind == RT_NODE_QUAD || n.kind == RT_NODE_TRIANGLE ||
-                                n.kind == RT_NODE_LIST /* a fused box */ ||
+                                n.kind == RT_NODE_LIST /* a fused box */ || is_obox(l.id) ||
                                 (n.kind == RT_NODE_MEDIUM && d_.nodes[n.a].kind == RT_NODE_SPHERE && d_.spheres[d_.nodes[n.a].a].dcenter[0] == 0 &&
                                  d_.spheres[d_.nodes[n.a].a].dcenter[1] == 0 && d_.spheres[d_.nodes[n.a].a].dcenter[2] == 0);
             if (!simple) return fail(RT_ERR_UNSUPPORTED, "device build: node " + std::to_string(l.id) + " is not a single record (instance or general medium)");
@@ -468,6 +468,32 @@ template <class R> class Flattener {
             o[2] = -s * p[0] + c * p[2] + t[2];
         }
     };
+    // translate(rotate_y(box())), rotate_y(box()) or translate(box()) -- the way the reference places a box (cpuRenderer.cpp:
+    // cornell_box, cornell_smoke) -- with a box that match_box() accepts: one OBOX record (f32 stream).  sn, cs, t: the
+    // instance's rotation (identity: 0, 1) and offset (0 if none).
+    bool is_obox(int id) const {
+        const int k = d_.nodes[id].kind;
+        int box;
+        double sn, cs, t[3];
+        return fuse_ && (k == RT_NODE_TRANSLATE || k == RT_NODE_ROTATE_Y) && !std::getenv("RT_AMD_NO_OBOX") && match_obox(id, box, sn, cs, t);
+    }
+    bool match_obox(int id, int &box, double &sn, double &cs, double t[3]) const {
+        const rt_node *n = &d_.nodes[id];
+        sn = 0; cs = 1; t[0] = t[1] = t[2] = 0;
+        if (n->kind == RT_NODE_TRANSLATE) {
+            for (int a = 0; a < 3; a++) t[a] = n->p[a];
+            n = &d_.nodes[n->a];
+        }
+        if (n->kind == RT_NODE_ROTATE_Y) {
+            sn = n->p[0]; cs = n->p[1];
+            n = &d_.nodes[n->a];
+        }
+        if (n->kind != RT_NODE_LIST) return false;
+        box = (int)(n - d_.nodes);
+        double lo[3], hi[3];
+        int mat, face_id[6], outward;
+        return match_box(box, lo, hi, mat, face_id, outward);
+    }
     bool bakeable(int id, int rdepth = 0) const {
         if (rdepth > 256) return false;
         const rt_node &n = d_.nodes[id];
@@ -1036,6 +1062,24 @@ template <class R> class Flattener {
         }
         case RT_NODE_TRANSLATE:
         case RT_NODE_ROTATE_Y: {
+            if (fuse_ && !std::getenv("RT_AMD_NO_OBOX")) {
+                int box;
+                double sn, cs, t[3];
+                if (match_obox(id, box, sn, cs, t)) {
+                    double lo[3], hi[3];
+                    int mat, face_id[6], outward;
+                    match_box(box, lo, hi, mat, face_id, outward);
+                    const int off = push_units(4, id);
+                    f_.stream[off] = UnitT<R>{{F(lo[0]), F(hi[0]), F(lo[1]), F(hi[1])}};
+                    f_.stream[off + 1] = UnitT<R>{{F(lo[2]), F(hi[2]), I(mat), I(make_hdr(K_OBOX, outward, ctx))}};
+                    f_.stream[off + 2] = UnitT<R>{{F(sn), F(cs), F(t[0]), F(t[1])}};
+                    f_.stream[off + 3] = UnitT<R>{{F(t[2]), R(0), R(0), R(0)}};
+                    f_.cold[off] = UnitT<R>{{I(face_id[0]), I(face_id[1]), I(face_id[2]), I(face_id[3])}};
+                    f_.cold[off + 1] = UnitT<R>{{I(face_id[4]), I(face_id[5]), I(0), I(0)}};
+                    f_.n_fused_boxes++;
+                    return RT_OK;
+                }
+            }
             if (rebuild_ && ctx == 0 && bakeable(id)) return emit_group(id, ctx, rdepth);
             if (fuse_ && ctx == 0 && bakeable(id)) {
                 double lo[3], hi[3];

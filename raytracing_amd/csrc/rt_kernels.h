@@ -657,6 +657,16 @@ RT_DEV void trav_leaf_step(const Mem<R, ALL_LDS> &mem, const SC &sc, Trav<R> &tv
                 tv.best_t = t; tv.best_off = i;
             }
         }
+    } else if (kind == K_OBOX) {
+        // translate(rotate_y(box())): hittable.h:53-65 moves the ray by -offset, hittable.h:110-124 turns it, quad.h:103's
+        // six quads are one slab test in that frame; t is the same number in both frames (rigid transforms, d not normalised)
+        const UnitT<R> u2 = mem.ld(i + 2 * U), u3 = mem.ld(i + 3 * U);
+        V3<R> o = tv.o, d = tv.d;
+        xf_apply(XF_TRANSLATE, u2.w[2], u2.w[3], u3.w[0], o, d);
+        xf_apply(XF_ROTATE_Y, u2.w[0], u2.w[1], R(0), o, d);
+        R t;
+        if (aabox_t(tv.u0, tv.u1, o, inv_dir_trav(d), tmin, tv.best_t, t)) { tv.best_t = t; tv.best_off = i; }
+        next = i + 4 * U;
     } else if (kind == K_XF_ENTER) {
         xf_apply(ldi(tv.u1.w[0]), tv.u0.w[0], tv.u0.w[1], tv.u0.w[2], tv.o, tv.d);
         tv.inv = inv_dir_trav(tv.d);
@@ -731,21 +741,30 @@ RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SC &sc, const RayT<R> &
         h.mat = ldi(u1.w[0]);
         if (want_all || sc.mat(h.mat).needs_uv) sphere_uv(outward, h.u, h.v);
         if (want_all) h.prim = ldi(cold_at(sc.cold, best_off).w[3]);
-    } else if (h.kind == K_AABOX) {
+    } else if (h.kind == K_AABOX || h.kind == K_OBOX) {
+        RayT<R> rb = r; // the ray in the box's frame
+        UnitT<R> u2{}, u3{};
+        if (h.kind == K_OBOX) {
+            u2 = mem.ld(best_off + 2 * U);
+            u3 = mem.ld(best_off + 3 * U);
+            xf_apply(XF_TRANSLATE, u2.w[2], u2.w[3], u3.w[0], rb.o, rb.d);
+            xf_apply(XF_ROTATE_Y, u2.w[0], u2.w[1], R(0), rb.o, rb.d);
+            h.p = ray_at(rb, best_t);
+        }
         // which face: the slab plane whose distance is the winning t
-        const V3<R> inv = inv_dir(r.d);
+        const V3<R> inv = inv_dir(rb.d);
         int face = 0;
         R err = Const<R>::inf;
         auto probe = [&](R plane, R ro, R ri, int f) {
             R e = m_abs((plane - ro) * ri - best_t);
             if (e < err) { err = e; face = f; }
         };
-        probe(u0.w[0], r.o.x, inv.x, 0);
-        probe(u0.w[1], r.o.x, inv.x, 1);
-        probe(u0.w[2], r.o.y, inv.y, 2);
-        probe(u0.w[3], r.o.y, inv.y, 3);
-        probe(u1.w[0], r.o.z, inv.z, 4);
-        probe(u1.w[1], r.o.z, inv.z, 5);
+        probe(u0.w[0], rb.o.x, inv.x, 0);
+        probe(u0.w[1], rb.o.x, inv.x, 1);
+        probe(u0.w[2], rb.o.y, inv.y, 2);
+        probe(u0.w[3], rb.o.y, inv.y, 3);
+        probe(u1.w[0], rb.o.z, inv.z, 4);
+        probe(u1.w[1], rb.o.z, inv.z, 5);
         // a box of no thickness is an axis-aligned quad (rt_flatten.h): its face is the flat axis', whatever edge the hit lies on
         if (u0.w[0] == u0.w[1]) face = 0;
         if (u0.w[2] == u0.w[3]) face = 2;
@@ -755,13 +774,18 @@ RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SC &sc, const RayT<R> &
         V3<R> outward = mk<R>(axis == 0 ? sgn : R(0), axis == 1 ? sgn : R(0), axis == 2 ? sgn : R(0));
         const bool stored_outward = (hdr_payload(hdr) >> face) & 1;
         const V3<R> n = stored_outward ? outward : -outward; // the quad's own normal (quad.h:15)
-        h.front = dot(r.d, n) < R(0);
+        h.front = dot(rb.d, n) < R(0);
         h.n = h.front ? n : -n;
         h.mat = ldi(u1.w[2]);
         if (want_all) {
             const UnitT<R> c = cold_at(sc.cold, best_off + (face >> 2) * U);
             const int k = face & 3;
             h.prim = ldi(k == 0 ? c.w[0] : (k == 1 ? c.w[1] : (k == 2 ? c.w[2] : c.w[3])));
+        }
+        if (h.kind == K_OBOX) { // back to the frame the record stands in: rotate (hittable.h:135-145), then the offset (hittable.h:62)
+            const R sn = u2.w[0], cs = u2.w[1];
+            h.p = mk<R>((cs * h.p.x) + (sn * h.p.z), h.p.y, (-sn * h.p.x) + (cs * h.p.z)) + mk<R>(u2.w[2], u2.w[3], u3.w[0]);
+            h.n = mk<R>((cs * h.n.x) + (sn * h.n.z), h.n.y, (-sn * h.n.x) + (cs * h.n.z));
         }
     } else if (h.kind == K_QUAD) {
         const UnitT<R> u2 = mem.ld(best_off + 2 * U), u3 = mem.ld(best_off + 3 * U), u4 = mem.ld(best_off + 4 * U);

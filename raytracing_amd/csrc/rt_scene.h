@@ -55,6 +55,7 @@ enum : int {
     K_XF_EXIT = 7,
     K_MSPHERE = 8, // moving sphere (3 units)
     K_MEDIUM_GEN = 9, // constant_medium whose boundary is not a static sphere: the boundary is a sub-stream of its own
+    K_OBOX = 10, // f32 stream: translate(rotate_y(box())) as ONE record (4 units): the AABOX in its own frame + sin, cos, offset
     K_IDLE = 14,
     K_READY = 15,
 };

@@ -1,7 +1,7 @@
 """Structure checks of a float record stream (test infrastructure; layout: raytracing_amd/csrc/rt_scene.h)."""
 import numpy as np
 
-_UNITS = {0: 2, 1: 2, 2: 2, 3: 2, 4: 5, 5: 3, 6: 2, 7: 2, 8: 3, 9: 2, 15: 2}  # units per record kind (csrc/rt_scene.h)
+_UNITS = {0: 2, 1: 2, 2: 2, 3: 2, 4: 5, 5: 3, 6: 2, 7: 2, 8: 3, 9: 2, 10: 4, 15: 2}  # units per record kind (csrc/rt_scene.h)
 
 
 def records(units):

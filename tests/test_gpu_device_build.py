@@ -21,7 +21,7 @@ def _scene(n):
     return random_scene.build(int(n.split()[1]), single_records=True) if isinstance(n, str) else fx.scene(n)
 
 
-@pytest.mark.parametrize("n", [1, 3, 4, "random 1", "random 2"])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, "random 1", "random 2"])
 def test_device_built_stream_structure_and_hits(gpu_ctx, n):
     sc = _scene(n)
     t0 = time.perf_counter()
@@ -70,12 +70,14 @@ def test_device_built_stream_structure_and_hits(gpu_ctx, n):
         host.close()
 
 
-@pytest.mark.parametrize("n", [2, 6])
+@pytest.mark.parametrize("n", [6, "random 3 full"])
 def test_device_build_refuses_multi_record_leaves(gpu_ctx, n):
-    """cornell's rotated box (an instance that stays an instance) and cornell_smoke's box-bounded media are more than one
-    record per leaf: the device build says so (the caller uses rt_scene_upload)."""
+    """cornell_smoke's box-bounded media and an instance of a list of quads (an instance that stays an instance) are more
+    than one record per leaf: the device build says so (the caller uses rt_scene_upload).  (cornell_box's rotated box is
+    ONE record, an OBOX, and is taken: the structure test above.)"""
+    sc = random_scene.build(3) if isinstance(n, str) else fx.scene(n)
     with pytest.raises(lib.RtError):
-        gpu_ctx.upload(fx.scene(n), device_build=True)
+        gpu_ctx.upload(sc, device_build=True)
 
 
 def test_device_build_single_primitive_and_double_path(gpu_ctx):

@@ -13,9 +13,9 @@ import numpy as np  # noqa: E402
 from raytracing_amd import lib  # noqa: E402
 from tests import fixtures as fx  # noqa: E402
 
-K_BOX, K_SPHERE, K_AABOX, K_MEDIUM, K_QUAD, K_TRI, K_XF_ENTER, K_XF_EXIT, K_MSPHERE, K_MEDIUM_GEN, K_READY = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15
-NAMES = {0: "box", 1: "sphere", 2: "aabox", 3: "medium", 4: "quad", 5: "tri", 6: "xf_enter", 7: "xf_exit", 8: "msphere", 9: "medium_gen"}
-UNITS = {K_SPHERE: 2, K_AABOX: 2, K_MEDIUM: 2, K_QUAD: 5, K_TRI: 3, K_XF_ENTER: 2, K_XF_EXIT: 2, K_MSPHERE: 3, K_MEDIUM_GEN: 2}
+K_BOX, K_SPHERE, K_AABOX, K_MEDIUM, K_QUAD, K_TRI, K_XF_ENTER, K_XF_EXIT, K_MSPHERE, K_MEDIUM_GEN, K_OBOX, K_READY = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15
+NAMES = {0: "box", 1: "sphere", 2: "aabox", 3: "medium", 4: "quad", 5: "tri", 6: "xf_enter", 7: "xf_exit", 8: "msphere", 9: "medium_gen", 10: "obox"}
+UNITS = {K_SPHERE: 2, K_AABOX: 2, K_MEDIUM: 2, K_QUAD: 5, K_TRI: 3, K_XF_ENTER: 2, K_XF_EXIT: 2, K_MSPHERE: 3, K_MEDIUM_GEN: 2, K_OBOX: 4}
 
 
 def slab(lo, hi, o, d, tmin, tmax):
@@ -69,6 +69,18 @@ def walk(units_f, units_i, ids, ray, xi, counts, start=0, tmin=0.001):
                         break
         elif kind == K_AABOX:
             s = slab((u0[0], u0[2], u1[0]), (u0[1], u0[3], u1[1]), o, d, -math.inf, math.inf)
+            if s:
+                for cand in s:
+                    if tmin < cand < best_t:
+                        t = cand
+                        break
+        elif kind == K_OBOX:  # translate(rotate_y(box())): the ray moved by -offset and turned, then the slab test
+            u2, u3 = units_f[i + 2], units_f[i + 3]
+            sn, cs = float(u2[0]), float(u2[1])
+            oo = o - np.array([u2[2], u2[3], u3[0]], dtype=np.float64)
+            oo = np.array([cs * oo[0] - sn * oo[2], oo[1], sn * oo[0] + cs * oo[2]])
+            dd = np.array([cs * d[0] - sn * d[2], d[1], sn * d[0] + cs * d[2]])
+            s = slab((u0[0], u0[2], u1[0]), (u0[1], u0[3], u1[1]), oo, dd, -math.inf, math.inf)
             if s:
                 for cand in s:
                     if tmin < cand < best_t:
@@ -145,7 +157,7 @@ def main():
         t, off = walk(uf, ui, ids, rays[k], float(xi[k]), counts)
         prim = int(ids[off]) if off >= 0 else -1
         want = int(hits["prim"][k])
-        if prim != want and (ui[off + 1, 3] & 15) != K_AABOX:  # (an AABOX record stands for six quads)
+        if prim != want and (ui[off + 1, 3] & 15) not in (K_AABOX, K_OBOX):  # (an AABOX record stands for six quads)
             if not (want >= 0 and prim >= 0 and abs(t - float(hits["t"][k])) <= 1e-4 * abs(t)):
                 wrong += 1
     print(f"{m} rays; steps per ray: " + ", ".join(f"{NAMES[k]} {v / m:.2f}" for k, v in sorted(counts.items())) +
