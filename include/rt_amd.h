@@ -230,7 +230,8 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out);
  * are rebuilt per frame.  Replaces bvh_node's constructor (bvh.h:15-41: random axis, std::sort, median split; the
  * reference's CUDA tree builds on the device as well, src/cuda/bvh.h:140-188) for the production (f32) path; closest hits
  * do not depend on the hierarchy.  RT_ERR_UNSUPPORTED if a leaf of the scene is more than one record (an instance that
- * cannot be emitted in world space, a constant_medium whose boundary is not a static sphere): use rt_scene_upload. */
+ * is neither emitted in world space -- spheres, triangles -- nor a translate / rotate_y of one box(); a constant_medium
+ * whose boundary is not a static sphere): use rt_scene_upload. */
 int rt_scene_upload_device_build(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out);
 void rt_scene_free(rt_scene *scene);
 /* out[4] = { threaded device nodes, lights, f32 device bytes, f64 device bytes (0 until a call first asks for
