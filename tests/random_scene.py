@@ -44,6 +44,14 @@ class _Builder:
         lo, hi = pts.min(0) - 5e-5, pts.max(0) + 5e-5
         return self.node(abi.RT_NODE_TRIANGLE, len(self.triangles) - 1, bbox=(lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]))
 
+    def box(self, a, b, mat=0):
+        """quad.h:103 box(): the six quads in the reference's order, as a list"""
+        lo, hi = np.minimum(a, b).astype(np.float64), np.maximum(a, b).astype(np.float64)
+        dx, dy, dz = np.array([hi[0] - lo[0], 0, 0]), np.array([0, hi[1] - lo[1], 0]), np.array([0, 0, hi[2] - lo[2]])
+        return self.list([self.quad((lo[0], lo[1], hi[2]), dx, dy, mat), self.quad((hi[0], lo[1], hi[2]), -dz, dy, mat),
+                          self.quad((hi[0], lo[1], lo[2]), -dx, dy, mat), self.quad((lo[0], lo[1], lo[2]), dz, dy, mat),
+                          self.quad((lo[0], hi[1], hi[2]), dx, -dz, mat), self.quad((lo[0], lo[1], lo[2]), dx, dz, mat)])
+
     def list(self, kids):
         a = len(self.child_index)
         self.child_index += list(kids)
@@ -89,6 +97,12 @@ def build(seed: int, n_spheres: int = 240, single_records: bool = False) -> abi.
     walls = b.list([b.quad(rng.uniform(-4, 4, size=3), rng.normal(size=3) * 3, rng.normal(size=3) * 3) for _ in range(6)])
     if not single_records:
         top.append(b.node(abi.RT_NODE_TRANSLATE, b.node(abi.RT_NODE_ROTATE_Y, walls, p=(math.sin(-th), math.cos(-th), 0, 0)), p=(-25, 6, 12, 0)))
+    # boxes: a plain box() (one AABOX record), and the ways the reference places one (one OBOX record each)
+    top.append(b.box((-38, -6, 20), (-30, 4, 31)))
+    th2 = math.radians(-18.0)
+    top.append(b.node(abi.RT_NODE_TRANSLATE, b.node(abi.RT_NODE_ROTATE_Y, b.box((0, 0, 0), (9, 17, 8)), p=(math.sin(th2), math.cos(th2), 0, 0)), p=(12, -4, -30, 0)))
+    top.append(b.node(abi.RT_NODE_ROTATE_Y, b.box((20, 0, 20), (26, 5, 29)), p=(math.sin(th), math.cos(th), 0, 0)))
+    top.append(b.node(abi.RT_NODE_TRANSLATE, b.box((0, 0, 0), (5, 5, 5)), p=(-12, 15, 3, 0)))
     world = b.list(top)
     light = b.quad((-5, 70, -5), (10, 0, 0), (0, 0, 10), mat=2)
     arrays = {
