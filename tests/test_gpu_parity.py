@@ -220,6 +220,22 @@ def test_ragged_image_sizes(scenes):
         np.testing.assert_allclose(acc, want, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("depth", [0, 1, 2])
+def test_depth_limits_match_oracle(scenes, depth):
+    """camera.h:294-295: depth 0 returns black before anything is hit; depth 1 sees only what emits (or the background)."""
+    from raytracing_amd import camera
+    for n in (1, 2):
+        cam = camera.scene_camera(n, 24, 16, 4, depth)
+        want, _ = O.render(fx.scene(n), cam, seed=3, rng_mode=1)
+        acc, _, st = scenes[n].render(cam, seed=3, precision=abi.RT_PREC_F64)
+        np.testing.assert_allclose(acc, want, rtol=1e-6, atol=1e-7)
+        acc32, _, st32 = scenes[n].render(cam, seed=3, precision=abi.RT_PREC_F32)
+        if depth == 0:
+            assert not acc.any() and not acc32.any() and st["rays"] == 0 and st32["rays"] == 0
+        else:
+            assert st32["rays"] == st["rays"] or abs(st32["rays"] - st["rays"]) <= 0.02 * st["rays"]
+
+
 def test_bad_arguments_return_status(gpu_ctx, scenes):
     from raytracing_amd import lib
     cam, _, _, _ = fx.img(2)
