@@ -261,11 +261,11 @@ template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, Device
     s.n_units = (int)f.stream.size();
     int cap = LaunchCfg<R>::lds_bytes / (int)sizeof(UnitT<R>);
     if (ctx->lds_limit_units >= 0 && ctx->lds_limit_units < cap) cap = ctx->lds_limit_units;
-    s.lds_units = s.n_units < cap ? s.n_units : cap;
+    // the stream is staged into LDS whole or not at all (rt_kernels.h, Mem); the shading tables whenever they fit behind it
+    s.lds_units = s.n_units <= cap ? s.n_units : 0;
     s.tab = base + o_xf;
     s.tab_bytes = (int32_t)tab_bytes;
-    s.tab_in_lds = (s.lds_units == s.n_units && ctx->lds_limit_units < 0 &&
-                    (size_t)s.n_units * sizeof(UnitT<R>) + tab_bytes <= (size_t)LaunchCfg<R>::lds_bytes) ? 1 : 0;
+    s.tab_in_lds = ((size_t)s.lds_units * sizeof(UnitT<R>) + tab_bytes <= (size_t)LaunchCfg<R>::lds_bytes && !std::getenv("RT_AMD_NO_TAB_LDS")) ? 1 : 0;
     s.n_lights = (int)f.lights.size();
     s.lights_is_list = f.lights_is_list;
     s.has_gen_medium = f.has_gen_medium;

@@ -246,14 +246,10 @@ template <class R, bool ALL_LDS> struct Mem {
         if constexpr (ALL_LDS) {
             return ld_unit(reinterpret_cast<const UnitT<R> *>(l + pos));
         } else {
-            UnitT<R> u;
-            if (pos < lds_bytes) {
-                u = ld_unit(reinterpret_cast<const UnitT<R> *>(l + pos));
-            } else {
-                asm volatile("" : "+v"(pos)); // keep the two address spaces in separate blocks (no pointer select -> flat load)
-                u = ld_unit(reinterpret_cast<const UnitT<R> *>(reinterpret_cast<const unsigned char *>(glob) + pos));
-            }
-            return u;
+            // a stream that does not fit is read from global memory as a whole (its cache lines live in L2 / the vector L1):
+            // a resident PREFIX with a per-load address-space branch measured slower than no prefix at all (mesh_scene 444 vs
+            // 406 ms; final_scene forced to 98 % resident: 756 against 555 fully resident), and LDS then holds the tables
+            return ld_unit(reinterpret_cast<const UnitT<R> *>(reinterpret_cast<const unsigned char *>(glob) + pos));
         }
     }
 };

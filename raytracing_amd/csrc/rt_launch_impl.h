@@ -50,17 +50,19 @@ hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const Rende
     };
     // (the kernels that can walk a constant_medium's boundary sub-stream are separate instantiations: that walk keeps a
     // second traversal state alive, which the common scenes' kernels should not pay for in registers)
-    const bool all = sc.lds_units == sc.n_units, tab = all && sc.tab_in_lds;
+    const bool all = sc.lds_units == sc.n_units, tab = sc.tab_in_lds != 0;
 #if RT_QUEUES
     if constexpr (sizeof(R) == 4) { // experimental: rays regrouped across the waves of a workgroup (rt_kernel_q.h)
         if (cam.max_depth >= (1 << 22)) return hipErrorInvalidValue; // the bounce shares a word with the accumulator address
         if (sc.has_gen_medium) {
-            if (tab) e = go(render_kernel_q<true, true, true, C::block>);
+            if (all && tab) e = go(render_kernel_q<true, true, true, C::block>);
             else if (all) e = go(render_kernel_q<true, false, true, C::block>);
+            else if (tab) e = go(render_kernel_q<false, true, true, C::block>);
             else e = go(render_kernel_q<false, false, true, C::block>);
         } else {
-            if (tab) e = go(render_kernel_q<true, true, false, C::block>);
+            if (all && tab) e = go(render_kernel_q<true, true, false, C::block>);
             else if (all) e = go(render_kernel_q<true, false, false, C::block>);
+            else if (tab) e = go(render_kernel_q<false, true, false, C::block>);
             else e = go(render_kernel_q<false, false, false, C::block>);
         }
         if (e != hipSuccess) return e;
@@ -68,12 +70,14 @@ hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const Rende
     }
 #endif
     if (sc.has_gen_medium) {
-        if (tab) e = go(render_kernel<R, true, true, true, C::block>);
+        if (all && tab) e = go(render_kernel<R, true, true, true, C::block>);
         else if (all) e = go(render_kernel<R, true, false, true, C::block>);
+        else if (tab) e = go(render_kernel<R, false, true, true, C::block>);
         else e = go(render_kernel<R, false, false, true, C::block>);
     } else {
-        if (tab) e = go(render_kernel<R, true, true, false, C::block>);
+        if (all && tab) e = go(render_kernel<R, true, true, false, C::block>);
         else if (all) e = go(render_kernel<R, true, false, false, C::block>);
+        else if (tab) e = go(render_kernel<R, false, true, false, C::block>);
         else e = go(render_kernel<R, false, false, false, C::block>);
     }
     if (e != hipSuccess) return e;
@@ -100,14 +104,16 @@ hipError_t launch_trace(const SceneT<R> &sc, const rt_ray *d_rays, const double 
         hipLaunchKernelGGL(k, grid, block, lds + C::stream_off, stream, sc, d_rays, d_xi, n, d_out, a);
         return hipSuccess;
     };
-    const bool all = sc.lds_units == sc.n_units, tab = all && sc.tab_in_lds;
+    const bool all = sc.lds_units == sc.n_units, tab = sc.tab_in_lds != 0;
     if (sc.has_gen_medium) {
-        if (tab) e = go(trace_kernel<R, true, true, true, C::block>);
+        if (all && tab) e = go(trace_kernel<R, true, true, true, C::block>);
         else if (all) e = go(trace_kernel<R, true, false, true, C::block>);
+        else if (tab) e = go(trace_kernel<R, false, true, true, C::block>);
         else e = go(trace_kernel<R, false, false, true, C::block>);
     } else {
-        if (tab) e = go(trace_kernel<R, true, true, false, C::block>);
+        if (all && tab) e = go(trace_kernel<R, true, true, false, C::block>);
         else if (all) e = go(trace_kernel<R, true, false, false, C::block>);
+        else if (tab) e = go(trace_kernel<R, false, true, false, C::block>);
         else e = go(trace_kernel<R, false, false, false, C::block>);
     }
     if (e != hipSuccess) return e;
