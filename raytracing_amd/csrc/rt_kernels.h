@@ -214,8 +214,8 @@ template <class R> RT_DEV R medium_draw(uint32_t k0, uint32_t k1, uint32_t pixel
 }
 
 // ------------------------------------------------------------------------------------------------ scene memory
-// The leading sc.lds_units units of the record stream live in LDS (staged by stage_stream()), the rest in global
-// memory.  ALL_LDS = the whole stream fits: no per-load address-space branch.
+// The record stream lives in LDS (ALL_LDS: it fits, staged by stage_scene()) or in global memory, as a whole either way:
+// no per-load address-space branch.
 extern __shared__ __attribute__((aligned(16))) unsigned char rt_smem[];
 
 template <class R> RT_DEV int ldi(R x) { return dec_int(x); }
@@ -278,7 +278,7 @@ template <class R, bool TAB_LDS> struct SceneV {
     RT_DEV const LightT<R> &light(int i) const { return at<LightT<R>>(o_lights)[i]; }
 };
 
-// Stage the stream prefix (and, for TAB_LDS, the shading tables) into LDS; returns the kernels' view of the tables.
+// Stage the stream (if it is to live there) and, for TAB_LDS, the shading tables into LDS; returns the kernels' view of the tables.
 template <class R, bool TAB_LDS> RT_DEV SceneV<R, TAB_LDS> stage_scene(const SceneT<R> &sc) {
     UnitT<R> *l = reinterpret_cast<UnitT<R> *>(rt_smem + LdsLayout<R>::stream_off);
     for (int k = threadIdx.x; k < sc.lds_units; k += blockDim.x) l[k] = sc.stream[k];

@@ -18,7 +18,7 @@ struct RenderLaunch {
 };
 
 // Workgroup size and LDS budget of the kernels of precision R: see LdsLayout (rt_scene.h).  lds_bytes is what the
-// scene (stream prefix + shading tables) may take; every launch asks for stream_off + the scene's bytes.
+// scene (stream + shading tables) may take; every launch asks for stream_off + the scene's bytes.
 template <class R> struct LaunchCfg {
     static constexpr int block = LdsLayout<R>::block;
     static constexpr int lds_bytes = LdsLayout<R>::scene_bytes;

@@ -9,8 +9,8 @@
 // The stream is an array of UNITS of four scalars (f32: 16 B = one ds_read_b128 / global_load_dwordx4, f64: 32 B).
 // Primitives are stored inline in the stream (no second dependent fetch), every record is >= 2 units and keeps its
 // header (kind | payload << 4) in the last scalar of its second unit, so one traversal step always starts with the
-// same two unit loads.  The leading `lds_units` units of the stream are staged into the CU's LDS (160 KiB) by every
-// workgroup; the remainder (large meshes) is read from global memory through L1/L2.
+// same two unit loads.  A stream that fits is staged into the CU's LDS (160 KiB) by every workgroup (`lds_units` ==
+// `n_units`); one that does not (large meshes) is read from global memory through L1/L2 as a whole (`lds_units` == 0).
 //
 //   record            units  unit0                     unit1                              unit2..
 //   BOX     (bvh_node)   2   x.min, x.max, y.min, y.max   z.min, z.max, skip, hdr          (min/max pairs: packed f32 math;
@@ -196,7 +196,7 @@ template <class R> struct SceneT { // device pointers; passed to kernels by valu
     int32_t tab_bytes;
     int32_t tab_in_lds;
     int32_t n_units;
-    int32_t lds_units; // leading units of `stream` that the kernels stage into LDS
+    int32_t lds_units; // units of `stream` that the kernels stage into LDS: all of them or none
     int32_t n_lights;
     int32_t lights_is_list; // lights_root is a hittable_list (hittable_list.h:52 draws the pick) vs a bare shape
     int32_t has_gen_medium; // MEDIUM_GEN records present: launch the kernels that can walk a boundary sub-stream
@@ -207,7 +207,7 @@ template <class R> struct SceneT { // device pointers; passed to kernels by valu
 //                              bytes (f32 kernels: 64-bit fixed point, so that a pixel's sum does not depend on the order
 //                              of the adds; f64 kernels: double), then the wave's item state (4 ints per slot + 16 + the
 //                              slots' NaN flags)
-//   [stream_off, ...)          the leading lds_units units of the record stream, then (when they fit) the shading tables
+//   [stream_off, ...)          the record stream (when it fits: whole or not at all), then (when they fit) the shading tables
 // RT_QUEUES (experimental float render kernel, rt_kernel_q.h): finished rays and new rays travel between the waves of a
 // workgroup through two ring buffers in LDS, in front of the stream; eight accumulator slots per wave make room for them.
 #ifndef RT_QUEUES
@@ -249,7 +249,7 @@ template <class R> struct LdsLayout {
     static constexpr int queue_bytes = (RT_QUEUES && sizeof(R) == 4) ? 2 * q_ring_bytes + 64 : 0;
     static constexpr int stream_off = queue_off + queue_bytes;
     static constexpr int total_bytes = sizeof(R) == 4 ? 160 * 1024 - 512 : 160 * 1024 - 512 - 16 * 1024;
-    static constexpr int scene_bytes = total_bytes - stream_off;               // stream prefix + tables
+    static constexpr int scene_bytes = total_bytes - stream_off;               // stream + tables
     static_assert(stream_off % 16 == 0 && stream_off < 65536 - 64, "ds_read immediate offset");
 };
 
