@@ -28,7 +28,8 @@ hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const Rende
     // A stream of a few records (cornell_box: 14, no BOX among them) is walked by all lanes in step: the shading trips are
     // what costs, and fuller ones pay (cornell_box 600 x 600 @1000: 83.6 ms at 40 waiting lanes, 79.2 at 52, 76.9 at 56,
     // 76.8 at 60; every larger scene is slower above 44: first_scene 120 -> 154 at 56, final_scene 562 -> 657).
-    a.shade_t = sc.n_units <= 64 ? 56 : RT_SHADE_T;
+    // (a stream read from global memory: mesh_scene 314 ms at 40, 308-309 at 28 ... 36)
+    a.shade_t = sc.n_units <= 64 ? 56 : (sc.lds_units != sc.n_units ? 32 : RT_SHADE_T);
     if (const char *e = std::getenv("RT_AMD_SHADE_T")) a.shade_t = std::atoi(e); // development knob
     for (int k = 0; k <= RT_MAX_SCHED_CHUNKS; k++) a.chunk_start[k] = rl.chunk_start[k];
     if (rl.chunk_size == 0 && (rl.n_chunks < 1 || rl.n_chunks > RT_MAX_SCHED_CHUNKS)) return hipErrorInvalidValue;
