@@ -227,7 +227,7 @@ int rt_abi_sizeof(const char *name);
 int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out);
 /* rt_scene_upload with the float stream's bounding-volume hierarchy built ON THE DEVICE (Morton keys, radix sort, a
  * binary radix tree, boxes fitted bottom-up, the threaded stream written in place) instead of on the host: for scenes that
- * are rebuilt per frame.  Replaces bvh_node's constructor (bvh.h:15-41: random axis, std::sort, median split; the
+ * are rebuilt per frame.  Replaces bvh_node's constructor (bvh.h:15-41: longest axis of the node's box, std::sort, median split; the
  * reference's CUDA tree builds on the device as well, src/cuda/bvh.h:140-188) for the production (f32) path; closest hits
  * do not depend on the hierarchy.  RT_ERR_UNSUPPORTED if a leaf of the scene is more than one record (an instance that
  * is neither emitted in world space -- spheres, triangles -- nor a translate / rotate_y of one box(); a constant_medium
@@ -242,16 +242,18 @@ int rt_scene_info(const rt_scene *scene, int32_t *out);
  * out[0] = record-stream units of the f32 (production) stream, out[1] = units of the f64 (parity) stream,
  * out[2] = box() lists fused into one AABOX record in the f32 stream (quad.h:103), out[3] = lights,
  * out[4] = translate / rotate_y instances of plain spheres emitted in world space in the f32 stream (hittable.h:45,76).
- * `out` holds 5 values.
+ * `out` holds 5 values.  reference_order != 0: the f32 stream as it would be with the reference's own bvh_nodes and visiting
+ * order instead of the flattener's hierarchy (what the structure tests compare the production stream against).
  * Returns RT_OK or the status rt_scene_upload would return for this description.  No reference counterpart. */
-int rt_scene_flatten_info(const rt_scene_desc *desc, int32_t *out);
+int rt_scene_flatten_info(const rt_scene_desc *desc, int reference_order, int32_t *out);
 
 /* Host-only (no GPU, no context): the f32 (production) record stream rt_scene_upload would put on the device, for
  * structure tests and traversal statistics: 16-byte units of four 32-bit words (layout: raytracing_amd/csrc/rt_scene.h).
  * Copies at most `cap_units` units into `units` (may be NULL with cap_units 0) and the description node id of the
  * record that starts at each unit (or -1) into `node_ids` (may be NULL); *n_units = size of the whole stream.
- * No reference counterpart. */
-int rt_scene_flatten_stream(const rt_scene_desc *desc, void *units, int32_t *node_ids, size_t cap_units, size_t *n_units);
+ * reference_order: as for rt_scene_flatten_info.  No reference counterpart. */
+int rt_scene_flatten_stream(const rt_scene_desc *desc, int reference_order, void *units, int32_t *node_ids, size_t cap_units,
+                            size_t *n_units);
 /* The same view of an UPLOADED scene's f32 stream, copied back from the device (the stream of
  * rt_scene_upload_device_build exists nowhere else).  No reference counterpart. */
 int rt_scene_download_stream(const rt_scene *scene, void *units, int32_t *node_ids, size_t cap_units, size_t *n_units);
@@ -275,11 +277,14 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
  * kernels, asynchronous on `stream`; it calls no hipMalloc / hipFree.  What rt_render_device keeps in buffers it
  * allocates -- the kernels' counters and the per-chunk partial frames -- lives in a file-scope __device__ array of
  * 64 MiB that each GPU the library runs on holds until the process ends (4 KiB of counters + partial frames).
- * Limits: one partial frame must fit, image_width * image_height * 3 cells <= 64 MiB - 4 KiB with 8-byte cells at
- * RT_PREC_F32 (2 796 032 pixels: 1920x1080 fits, as a single sample chunk) and 4-byte cells at RT_PREC_F64 (5 592 064
- * pixels), else RT_ERR_INVALID with a message; RT_PREC_F64 only after an allocating call has built the scene's f64 stream.
+ * Limit: the partial frames (image_width * image_height * 3 cells each, 8-byte cells at RT_PREC_F32, 4-byte at RT_PREC_F64)
+ * must fit 64 MiB - 4 KiB, so the sample range is cut into at most floor(that / one frame) chunks; a frame of which not
+ * even two fit -- 1920x1080 at RT_PREC_F32 is 49.8 MB -- renders as ONE chunk straight into d_accum, whatever its size
+ * (cost: the kernel ends on long work items instead of the decreasing schedule's short ones, a few percent at 1080p).
+ * RT_PREC_F64 only after an allocating call has built the scene's f64 stream (else RT_ERR_INVALID with a message).
  * The array is shared by every call on that GPU and keeps the last call's contents (the entry point clears what must
- * start at zero): two calls that overlap on one GPU -- other streams, other contexts on the device -- race.  No stats:
+ * start at zero): two calls that overlap on one GPU -- other streams, other contexts on the device -- race (rt_init of
+ * another context on the device does not touch the array).  No stats:
  * reading the ray counter back would synchronise. */
 int rt_render_static(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_params *params,
                      float *d_accum, void *stream);

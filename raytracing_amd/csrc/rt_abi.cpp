@@ -26,6 +26,7 @@ using namespace rtamd;
 // at its own address until the process ends.  In host code the NAME below is only a stand-in for hipGetSymbolAddress --
 // rt_init asks for the address once per context, with the context's device current -- and everything else (kernel
 // arguments, hipMemsetAsync) uses that pointer, never the name.
+enum : int { RT_N_COUNTERS = 64 }; // [0] rays, [1] the work-item cursor, [3..] diagnostic builds
 enum : size_t { RT_STATIC_COUNTER_BYTES = 4096, RT_STATIC_SCRATCH_BYTES = (size_t)64 << 20 };
 static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
 
@@ -134,12 +135,12 @@ double wall_ms() {
 
 // device_build (float stream only): the hierarchy is built on the device from the leaf records (rt_build.h)
 template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, DeviceScene<R> &ds, bool device_build = false) {
-    const bool timing = std::getenv("RT_AMD_TIMING") != nullptr; // development aid: where an upload's time goes
+    const bool timing = dev_knob("RT_AMD_TIMING") != nullptr; // development aid: where an upload's time goes
     const double t0 = wall_ms();
     Flat<R> f;
     std::string err;
     // RT_AMD_REF_ORDER (development knob): the float stream keeps the reference's bvh_nodes and visiting order
-    Flattener<R> fl(*desc, f, err, /*fuse_boxes=*/sizeof(R) == 4, /*own_hierarchy=*/sizeof(R) == 4 && !std::getenv("RT_AMD_REF_ORDER"));
+    Flattener<R> fl(*desc, f, err, /*fuse_boxes=*/sizeof(R) == 4, /*own_hierarchy=*/sizeof(R) == 4 && !dev_knob("RT_AMD_REF_ORDER"));
     std::vector<typename Flattener<R>::LeafRecord> leaves;
     std::vector<UnitT<R>> leaf_units, leaf_cold;
     double box_pad = 0;
@@ -159,8 +160,8 @@ template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, Device
         };
         std::vector<char> is_top(leaves.size(), 0);
         double top_share = 0.3; // (0.5: mesh_scene 602 ms, its walls stay in the tree; 0.3: 489; 0.2: the bounce frame 83 -> 90)
-        if (const char *e = std::getenv("RT_AMD_TOP_LEAF_SHARE")) top_share = std::atof(e); // development knob
-        for (int round = 0; round < 8 && !std::getenv("RT_AMD_NO_TOP_LEAVES"); round++) {
+        if (const char *e = dev_knob("RT_AMD_TOP_LEAF_SHARE")) top_share = std::atof(e); // development knob
+        for (int round = 0; round < 8 && !dev_knob("RT_AMD_NO_TOP_LEAVES"); round++) {
             double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, best = -1;
             size_t arg = 0, left = 0;
             for (size_t k = 0; k < leaves.size(); k++) {
@@ -265,7 +266,7 @@ template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, Device
     s.lds_units = s.n_units <= cap ? s.n_units : 0;
     s.tab = base + o_xf;
     s.tab_bytes = (int32_t)tab_bytes;
-    s.tab_in_lds = ((size_t)s.lds_units * sizeof(UnitT<R>) + tab_bytes <= (size_t)LaunchCfg<R>::lds_bytes && !std::getenv("RT_AMD_NO_TAB_LDS")) ? 1 : 0;
+    s.tab_in_lds = ((size_t)s.lds_units * sizeof(UnitT<R>) + tab_bytes <= (size_t)LaunchCfg<R>::lds_bytes && !dev_knob("RT_AMD_NO_TAB_LDS")) ? 1 : 0;
     s.n_lights = (int)f.lights.size();
     s.lights_is_list = f.lights_is_list;
     s.has_gen_medium = f.has_gen_medium;
@@ -395,11 +396,11 @@ int enqueue_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, int
     pl.rl.out_i64 = (precision == RT_PREC_F32 && pl.n_chunks > 1) ? 1 : 0;
     if (pl.n_samples == 0) {
         HIP_TRY(ctx, hipMemsetAsync(d_accum, 0, pl.n_px * 3 * sizeof(float), stream));
-        HIP_TRY(ctx, hipMemsetAsync(counters, 0, 40 * sizeof(unsigned long long), stream));
+        HIP_TRY(ctx, hipMemsetAsync(counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream));
         return RT_OK;
     }
     void *target = pl.n_chunks > 1 ? partial : (void *)d_accum;
-    HIP_TRY(ctx, hipMemsetAsync(counters, 0, 40 * sizeof(unsigned long long), stream));
+    HIP_TRY(ctx, hipMemsetAsync(counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipMemsetAsync(counters + 37, 0xff, sizeof(unsigned long long), stream)); // [37]: a minimum (diagnostic builds)
     if (precision == RT_PREC_F64)
         HIP_TRY(ctx, launch_render<double>(scene->f64.sc, convert_camera<double>(*cam), pl.rl, target, counters, stream));
@@ -410,12 +411,8 @@ int enqueue_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, int
 }
 
 void print_profile(rt_ctx *ctx, const unsigned long long *c) { // diagnostic builds (-DRT_PROFILE_*) fill counters[3..39]
-    if (std::getenv("RT_AMD_PROFILE_ACTIONS")) {
-#if RT_QUEUES
-        const char *nm[6] = {"box", "leaf", "exchange", "nap", "-", "shade+deal"};
-#else
+    if (dev_knob("RT_AMD_PROFILE_ACTIONS")) {
         const char *nm[6] = {"box", "leaf", "leaf/aabox", "leaf/medium", "leaf/other", "shade+deal"};
-#endif
         for (int k = 0; k < 6; k++)
             std::fprintf(stderr, "[rt_amd profile] %-11s cycles %.4g (%.1f%% of wave time) trips %.4g cyc/trip %.1f lanes/trip %.1f\n",
                          nm[k], (double)c[4 + 3 * k], 100.0 * (double)c[4 + 3 * k] / (double)(c[3] ? c[3] : 1), (double)c[5 + 3 * k],
@@ -424,17 +421,14 @@ void print_profile(rt_ctx *ctx, const unsigned long long *c) { // diagnostic bui
         std::fprintf(stderr, "[rt_amd profile] per trip: %.1f lanes idle (item tail), %.1f lanes waiting for shading, of 64; %.1f%% of trips after the item's last unit was dealt\n",
                      (double)c[33] / (double)(c[35] ? c[35] : 1), (double)c[34] / (double)(c[35] ? c[35] : 1), 100.0 * (double)c[36] / (double)(c[35] ? c[35] : 1));
     }
-#if RT_QUEUES
-    if (std::getenv("RT_AMD_PROFILE_ACTIONS"))
-        std::fprintf(stderr, "[rt_amd profile] rings, per trip: %.1f hits wait, %.1f rays wait, %.1f paths in the workgroup, %.1f room credits free\n",
-                     (double)c[22] / (double)(c[35] ? c[35] : 1), (double)c[23] / (double)(c[35] ? c[35] : 1),
-                     (double)c[24] / (double)(c[35] ? c[35] : 1), (double)c[25] / (double)(c[35] ? c[35] : 1));
-    if (std::getenv("RT_AMD_PROFILE_ACTIONS"))
-        std::fprintf(stderr, "[rt_amd profile] shading trip, cycles: take %.0f, hit records %.0f, deal %.0f, generate + scatter %.0f, put %.0f\n",
-                     (double)c[26] / (double)(c[20] ? c[20] : 1), (double)c[27] / (double)(c[20] ? c[20] : 1), (double)c[28] / (double)(c[20] ? c[20] : 1),
-                     (double)c[29] / (double)(c[20] ? c[20] : 1), (double)c[30] / (double)(c[20] ? c[20] : 1));
-#endif
-    if (std::getenv("RT_AMD_PROFILE_TAIL")) { // builds with -DRT_PROFILE_TAIL: wave end times
+    if (dev_knob("RT_AMD_PROFILE_SHADE")) { // builds with -DRT_PROFILE_SHADE: the stages of the shading trip
+        const char *nm[7] = {"hit records", "dealing", "noise (wave)", "generator", "camera rays", "scatter", "trav_begin+fog"};
+        const double trips = (double)(c[54] ? c[54] : 1);
+        for (int k = 0; k < 7; k++)
+            std::fprintf(stderr, "[rt_amd profile] shading/%-14s cycles/trip %.1f lanes/trip %.1f\n", nm[k], (double)c[40 + 2 * k] / trips,
+                         (double)c[41 + 2 * k] / trips);
+    }
+    if (dev_knob("RT_AMD_PROFILE_TAIL")) { // builds with -DRT_PROFILE_TAIL: wave end times
         const double span = (double)(c[38] - c[37]), n_waves = (double)ctx->n_cus * 16.0;
         std::fprintf(stderr, "[rt_amd profile] waves busy on average %.1f%% of the kernel's span (first start to last end); wave run time min %.1f%% max %.1f%% of the span\n",
                      span > 0 ? 100.0 * (double)c[39] / n_waves / span : 0.0, span > 0 ? 100.0 * (double)(~c[35]) / span : 0.0,
@@ -447,11 +441,9 @@ int collect_stats(rt_ctx *ctx, const RenderPlan &pl, const unsigned long long *c
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
     float ms = 0;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    unsigned long long c[40];
+    unsigned long long c[RT_N_COUNTERS];
     HIP_TRY(ctx, hipMemcpy(c, counters, sizeof(c), hipMemcpyDeviceToHost));
     if (pl.n_samples > 0) print_profile(ctx, c);
-    if (pl.n_samples > 0 && c[2] != 0) // (builds with RT_QUEUES: a wave gave up waiting on a ring -- a bug, not a property of the scene)
-        return set_err(ctx, RT_ERR_HIP, "render kernel: the ring protocol gave up (code " + std::to_string(c[2]) + ")");
     stats->samples = (uint64_t)pl.n_px * (uint64_t)pl.n_samples;
     stats->rays = pl.n_samples > 0 ? c[0] : 0;
     stats->kernel_ms = pl.n_samples > 0 ? ms : 0.0;
@@ -496,7 +488,7 @@ int rt_init(int device, rt_ctx **out) {
         delete ctx;
         return RT_ERR_HIP;
     }
-    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&ctx->counter, 40 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&ctx->counter, RT_N_COUNTERS * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         rt_shutdown(ctx);
         return RT_ERR_HIP;
@@ -505,7 +497,7 @@ int rt_init(int device, rt_ctx **out) {
     // 15 ms, 150 ms in the first process on a freshly booted box.  Paid here, with the other one-off costs of creating a
     // context, instead of inside the first frame's scene upload.
     {
-        const unsigned long long zeros[40] = {};
+        const unsigned long long zeros[RT_N_COUNTERS] = {};
         if (hipMemcpy(ctx->counter, zeros, sizeof(zeros), hipMemcpyHostToDevice) != hipSuccess) {
             rt_shutdown(ctx);
             return RT_ERR_HIP;
@@ -519,18 +511,22 @@ int rt_init(int device, rt_ctx **out) {
         return RT_ERR_HIP;
     }
     // ... and a copy of the size of a scene blob takes another path (pinned staging chunks, set up on its first use: 6 ms
-    // of the first upload, whatever its size).  The static scratch array is a destination that needs no allocation.
+    // of the first upload, whatever its size).  The destination is a buffer of this context's own, freed again: never the
+    // static scratch, which a render of another context on this device may be using.
     {
         const std::vector<unsigned char> warm((size_t)2 << 20, 0);
-        if (hipMemcpy(ctx->static_scratch + RT_STATIC_COUNTER_BYTES, warm.data(), warm.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        void *d_warm = nullptr;
+        if (hipMalloc(&d_warm, warm.size()) != hipSuccess || hipMemcpy(d_warm, warm.data(), warm.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            if (d_warm) (void)hipFree(d_warm);
             rt_shutdown(ctx);
             return RT_ERR_HIP;
         }
+        (void)hipFree(d_warm);
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cus = prop.multiProcessorCount;
-    if (const char *e1 = std::getenv("RT_AMD_LDS_UNITS")) ctx->lds_limit_units = std::atoi(e1);
-    if (const char *e5 = std::getenv("RT_AMD_CHUNKS")) std::sscanf(e5, "%d,%d,%d", &ctx->min_chunk, &ctx->chunk_divisor, &ctx->max_chunk);
+    if (const char *e1 = dev_knob("RT_AMD_LDS_UNITS")) ctx->lds_limit_units = std::atoi(e1);
+    if (const char *e5 = dev_knob("RT_AMD_CHUNKS")) std::sscanf(e5, "%d,%d,%d", &ctx->min_chunk, &ctx->chunk_divisor, &ctx->max_chunk);
     *out = ctx;
     return RT_OK;
 }
@@ -588,11 +584,12 @@ int rt_scene_info(const rt_scene *scene, int32_t *out /* [4]: flat nodes, lights
     return RT_OK;
 }
 
-int rt_scene_flatten_stream(const rt_scene_desc *desc, void *units, int32_t *node_ids, size_t cap_units, size_t *n_units) {
+int rt_scene_flatten_stream(const rt_scene_desc *desc, int reference_order, void *units, int32_t *node_ids, size_t cap_units,
+                            size_t *n_units) {
     if (!desc || !n_units || (cap_units > 0 && !units)) return RT_ERR_INVALID;
     std::string err;
     Flat<float> f;
-    int rc = Flattener<float>(*desc, f, err, true, !std::getenv("RT_AMD_REF_ORDER")).run();
+    int rc = Flattener<float>(*desc, f, err, true, !reference_order).run();
     if (rc) return rc;
     *n_units = f.stream.size();
     const size_t n = std::min(cap_units, f.stream.size());
@@ -619,11 +616,11 @@ int rt_scene_download_stream(const rt_scene *scene, void *units, int32_t *node_i
     return RT_OK;
 }
 
-int rt_scene_flatten_info(const rt_scene_desc *desc, int32_t *out) {
+int rt_scene_flatten_info(const rt_scene_desc *desc, int reference_order, int32_t *out) {
     if (!desc || !out) return RT_ERR_INVALID;
     std::string err;
     Flat<float> f32;
-    int rc = Flattener<float>(*desc, f32, err, true, !std::getenv("RT_AMD_REF_ORDER")).run();
+    int rc = Flattener<float>(*desc, f32, err, true, !reference_order).run();
     if (rc) return rc;
     Flat<double> f64;
     rc = Flattener<double>(*desc, f64, err, false).run();
@@ -696,22 +693,21 @@ int rt_render_static(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
     if (!ctx || !scene || !cam || !params || !d_accum) return set_err(ctx, RT_ERR_INVALID, "rt_render_static: null argument");
     if (scene->ctx != ctx) return set_err(ctx, RT_ERR_INVALID, "rt_render_static: the scene belongs to another context");
     if (cam->image_width <= 0 || cam->image_height <= 0) return set_err(ctx, RT_ERR_INVALID, "render: bad camera");
-    // the partial frames live in the static array: that bounds the image
+    // the partial frames live in the static array: that bounds the number of sample chunks.  A frame so large that not even
+    // two partial frames fit renders as ONE chunk, straight into d_accum (no scratch beyond the counters; the kernel then
+    // ends on long work items instead of the decreasing schedule's short ones: a few percent of a 1080p frame).
     const int prec_ok = params->precision == RT_PREC_F64 ? RT_PREC_F64 : RT_PREC_F32;
     const size_t frame_bytes = (size_t)cam->image_width * (size_t)cam->image_height * 3 * partial_cell_bytes(prec_ok);
     const size_t room = RT_STATIC_SCRATCH_BYTES - RT_STATIC_COUNTER_BYTES;
-    if (frame_bytes > room)
-        return set_err(ctx, RT_ERR_INVALID,
-                       "rt_render_static: a " + std::to_string(cam->image_width) + " x " + std::to_string(cam->image_height) +
-                           " frame needs " + std::to_string(frame_bytes) + " bytes of scratch per sample chunk; the static scratch holds " +
-                           std::to_string(room) + " (at most " + std::to_string(room / (3 * partial_cell_bytes(prec_ok))) +
-                           " pixels at this precision): use rt_render_device");
     if (params->precision == RT_PREC_F64 && !scene->have_f64)
         return set_err(ctx, RT_ERR_INVALID, "rt_render_static: the f64 stream of this scene is built (and allocated) by the first "
                                             "RT_PREC_F64 call of rt_render_device / rt_trace_batch; make that call first");
     RenderPlan pl;
-    int rc = plan_render(ctx, cam, params, (int)(room / frame_bytes), pl);
+    int rc = plan_render(ctx, cam, params, (int)std::min<size_t>(room / frame_bytes, 65535), pl); // (0 or 1: a single chunk)
     if (rc) return rc;
+    if (pl.n_chunks > 1 && (size_t)pl.n_chunks * frame_bytes > room) // (cannot happen: the plan honours its cap)
+        return set_err(ctx, RT_ERR_INVALID, "rt_render_static: " + std::to_string(pl.n_chunks) + " partial frames of " + std::to_string(frame_bytes) +
+                                                " bytes do not fit the static scratch (" + std::to_string(room) + " bytes): use rt_render_device");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // every use of the array's memory goes through the per-device pointer taken in rt_init
     unsigned long long *counters = reinterpret_cast<unsigned long long *>(ctx->static_scratch);

@@ -190,7 +190,7 @@ hipError_t build_stream_on_device(const BuildLeaf *d_leaves, int n, const UnitT<
     auto scale = [&](int a) { const float ext = c_hi[a] - c_lo[a]; return ext > 0.0f && ext < 3.0e38f ? 1024.0f / ext : 0.0f; };
     const int blocks = (n + TPB - 1) / TPB;
     int order = 5;
-    if (const char *e = getenv("RT_AMD_DEV_ORDER")) order = atoi(e); // development knob
+    if (const char *e = dev_knob("RT_AMD_DEV_ORDER")) order = atoi(e); // development knob
     do {
         e = hipMemsetAsync(tmp + o_int, 0xff, up(4 * (7 * ni + (size_t)n)), 0); // parents = -1 ...
         if (e != hipSuccess) break;

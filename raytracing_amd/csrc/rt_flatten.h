@@ -77,7 +77,7 @@ template <class R> class Flattener {
                 if (std::isfinite(v)) m = std::fmax(m, v);
             }
             box_pad_ = 32.0 * 5.9604644775390625e-08 * 2.0 * m;
-            if (const char *e = std::getenv("RT_AMD_BOX_PAD_ULPS")) box_pad_ = std::atof(e) * 5.9604644775390625e-08 * 2.0 * m; // development knob
+            if (const char *e = dev_knob("RT_AMD_BOX_PAD_ULPS")) box_pad_ = std::atof(e) * 5.9604644775390625e-08 * 2.0 * m; // development knob
         }
         primary_ = primary_medium();
         f_.xforms.push_back(XformT<R>{}); // context 0 = world space
@@ -475,7 +475,7 @@ template <class R> class Flattener {
         const int k = d_.nodes[id].kind;
         int box;
         double sn, cs, t[3];
-        return fuse_ && (k == RT_NODE_TRANSLATE || k == RT_NODE_ROTATE_Y) && !std::getenv("RT_AMD_NO_OBOX") && match_obox(id, box, sn, cs, t);
+        return fuse_ && (k == RT_NODE_TRANSLATE || k == RT_NODE_ROTATE_Y) && !dev_knob("RT_AMD_NO_OBOX") && match_obox(id, box, sn, cs, t);
     }
     bool match_obox(int id, int &box, double &sn, double &cs, double t[3]) const {
         const rt_node *n = &d_.nodes[id];
@@ -627,7 +627,7 @@ template <class R> class Flattener {
 
     // ---- the float stream's own hierarchy ---------------------------------------------------------------------------
     // world.hit() is "the closest hit over all primitives"; which boxes are tested on the way is the reference's choice
-    // (bvh.h:15-41: a RANDOM axis per node, the objects sorted along it and cut at the median; the world itself a flat list
+    // (bvh.h:15-41: the longest axis of each node's box, the objects sorted along it and cut at the median; the world itself a flat list
     // of eleven objects in final_scene), not part of the result.  The float stream therefore gets a hierarchy built for
     // the walk the kernel does: every primitive of a frame -- whatever bvh_nodes and hittable_lists it sits under, baked
     // instances included -- becomes a leaf, and a binned surface-area-heuristic build decides the BOX records.  An
@@ -832,12 +832,12 @@ template <class R> class Flattener {
         double overlap = 0.1;           // weight of the area the two sides of a split share, in the split's cost (0 -> 0.1:
                                         // final_scene 635 -> 623, cornell_box 105 -> 103, mesh_scene 477 -> 471; 1.0: 665)
         BuildKnobs() { // development knobs
-            if (const char *e = std::getenv("RT_AMD_BVH_T2")) thr2 = std::atof(e);
-            if (const char *e = std::getenv("RT_AMD_BVH_TN")) thrn = std::atof(e);
-            if (const char *e = std::getenv("RT_AMD_BVH_ORDER")) order = std::atoi(e);
-            if (const char *e = std::getenv("RT_AMD_BVH_AXIS_MIN")) axis_min = std::atof(e);
-            if (const char *e = std::getenv("RT_AMD_BVH_OVERLAP")) overlap = std::atof(e);
-            if (const char *e = std::getenv("RT_AMD_BVH_BINS")) bins = std::min(32, std::max(2, std::atoi(e)));
+            if (const char *e = dev_knob("RT_AMD_BVH_T2")) thr2 = std::atof(e);
+            if (const char *e = dev_knob("RT_AMD_BVH_TN")) thrn = std::atof(e);
+            if (const char *e = dev_knob("RT_AMD_BVH_ORDER")) order = std::atoi(e);
+            if (const char *e = dev_knob("RT_AMD_BVH_AXIS_MIN")) axis_min = std::atof(e);
+            if (const char *e = dev_knob("RT_AMD_BVH_OVERLAP")) overlap = std::atof(e);
+            if (const char *e = dev_knob("RT_AMD_BVH_BINS")) bins = std::min(32, std::max(2, std::atoi(e)));
         }
     };
     BuildKnobs knobs_;
@@ -1062,7 +1062,7 @@ template <class R> class Flattener {
         }
         case RT_NODE_TRANSLATE:
         case RT_NODE_ROTATE_Y: {
-            if (fuse_ && !std::getenv("RT_AMD_NO_OBOX")) {
+            if (fuse_ && !dev_knob("RT_AMD_NO_OBOX")) {
                 int box;
                 double sn, cs, t[3];
                 if (match_obox(id, box, sn, cs, t)) {
@@ -1146,7 +1146,7 @@ template <class R> class Flattener {
         case RT_NODE_QUAD: {
             const rt_quad &q = d_.quads[n.a];
             if (q.mat < 0) return fail(RT_ERR_INVALID, "world quad without material");
-            if (fuse_ && !std::getenv("RT_AMD_NO_FLAT_QUADS")) {
+            if (fuse_ && !dev_knob("RT_AMD_NO_FLAT_QUADS")) {
                 // An axis-aligned quad whose material never asks for rec.u / rec.v (walls, ceiling lights) is a box of no
                 // thickness: two units instead of five and the AABOX step instead of the general one.  The slab test accepts
                 // exactly the points of the plane inside the quad's edges, inclusive (quad.h:63-70: unit.contains); a ray

@@ -1126,6 +1126,23 @@ template <class R> RT_DEV RayT<R> get_ray(const CameraT<R> &cam, int i, int j, i
 #define RT_SUB_END(k, mask)
 #endif
 
+#ifdef RT_PROFILE_SHADE
+// stages of the shading trip: cycles and lanes of hit records / dealing / noise / generator / camera rays / scatter / trav_begin
+#define RT_SH_BEGIN()                                                                                                  \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                        \
+    unsigned long long t_sh = __builtin_amdgcn_s_memtime();
+#define RT_SH_END(k, pred)                                                                                             \
+    {                                                                                                                  \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                    \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                    \
+        sh_cyc[k] += t_ - t_sh; sh_lanes[k] += popc64(lane_mask(pred)); sh_trips += (k) == 0;                          \
+        t_sh = t_;                                                                                                     \
+    }
+#else
+#define RT_SH_BEGIN()
+#define RT_SH_END(k, pred)
+#endif
+
 // The part of camera::ray_color (camera.h:291-326) that follows world.hit(), written iteratively: radiance
 // L += beta * (emitted | background), beta *= attenuation * scattering_pdf / pdf -- in two halves, so that the render
 // kernel can deal new units to the lanes whose paths end BEFORE it runs the generator: one generator block then serves
@@ -1338,6 +1355,9 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     const unsigned long long t_wave0 = __builtin_amdgcn_s_memtime();
     unsigned long long prof_idle = 0, prof_ready = 0, prof_all = 0, prof_tail = 0;
     unsigned long long sub_cyc[A_COUNT] = {}, sub_trips[A_COUNT] = {}, sub_lanes[A_COUNT] = {};
+#endif
+#ifdef RT_PROFILE_SHADE
+    unsigned long long sh_cyc[8] = {}, sh_lanes[8] = {}, sh_trips = 0;
 #endif
     // Work: an item = (8 x RT_TILE_H pixel tile, chunk of the sample range) = TPX x samples UNITS, unit u = sample s0 + u / TPX
     // of the tile's pixel u % TPX.  Lanes do not own pixels: a lane whose path has ended takes the next unit (wave-level dealing:
@@ -1556,6 +1576,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     tv.hdr = K_IDLE;
                 };
                 // ---- 1
+                RT_SH_BEGIN();
                 Hit<R> h;
                 h.p = mk<R>(R(0), R(0), R(0));
                 h.mat = 0;
@@ -1569,6 +1590,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     scatter = shade_hit(mem, sc, cam, ray, tv.best_t, tv.best_off, beta, L, h);
                     if (!scatter) add_sample(L);
                 }
+                RT_SH_END(0, ready);
                 // ---- 2
                 bool fresh = false; // this lane was dealt a unit in this trip: pixel (fi, fj), sample smp
                 int fi = 0, fj = 0;
@@ -1645,6 +1667,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         units_left = next_unit < n_item_units ? n_item_units - next_unit : 0;
                     }
                 }
+                RT_SH_END(1, fresh);
                 // ---- 3
                 // (noise textures first, by the whole wave for one lane at a time: see perlin_turb_wave)
                 bool has_turb = false;
@@ -1671,6 +1694,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         }
                     }
                 }
+                RT_SH_END(2, has_turb);
                 if (scatter || fresh) {
                     if (fresh) bounce = 0;
                     Rng<R> g;
@@ -1678,6 +1702,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     g.k1 = a.k1;
                     g.begin_stream(pixel, (uint32_t)smp, fresh ? 0u : (0x80000000u | (uint32_t)bounce));
                     med_xi = g.fifth(); // for the ray that starts now
+                    RT_SH_END(3, true);
                     if (fresh) {
                         int sj = (int)((float)smp * (float)cam.recip_sqrt_spp); // s / sqrt_spp, s % sqrt_spp without an integer division
                         int si = smp - sj * cam.sqrt_spp;
@@ -1685,13 +1710,16 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         if (si >= cam.sqrt_spp) { sj++; si -= cam.sqrt_spp; }
                         ray = get_ray(cam, fi, fj, si, sj, g);
                         beta = mk<R>(R(1), R(1), R(1));
+                        RT_SH_END(4, true);
                     } else {
+                        RT_SH_END(4, false);
                         shade_scatter(sc, ray, h, beta, g, has_turb, turb);
                         bounce++;
                         if (bounce == cam.max_depth) { // depth exhausted: the recursion returns 0 here (camera.h:294-295)
                             add_sample(beta * mk<R>(R(0), R(0), R(0)));
                             scatter = false; // (the lane gets its next unit in the next shading trip)
                         }
+                        RT_SH_END(5, true);
                     }
                     if (fresh || scatter) {
                         rays++;
@@ -1717,6 +1745,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                                 trav_goto(mem, tv, tv.i + 2 * Pos<R>::unit);
                             }
                         }
+                        RT_SH_END(6, true);
                     }
                 }
             }
@@ -1745,6 +1774,15 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
         atomicAdd(&counters[39], t1 - t_tail0);
         atomicMax(&counters[36], t1 - t_tail0);
         atomicMax(&counters[35], ~(t1 - t_tail0)); // maximum of the complement = minimum duration (the counter starts at zero)
+    }
+#endif
+#ifdef RT_PROFILE_SHADE
+    if (lane == 0) {
+        for (int k = 0; k < 7; k++) {
+            atomicAdd(&counters[40 + 2 * k], sh_cyc[k]);
+            atomicAdd(&counters[41 + 2 * k], sh_lanes[k]);
+        }
+        atomicAdd(&counters[54], sh_trips);
     }
 #endif
 #ifdef RT_PROFILE_ACTIONS
@@ -1812,10 +1850,6 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(SceneT<R> sc_arg, const rt
         out[k] = o;
     }
 }
-
-#if RT_QUEUES
-#include "rt_kernel_q.h"
-#endif
 
 } // namespace rtamd
 #endif

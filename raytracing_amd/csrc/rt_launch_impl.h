@@ -30,7 +30,7 @@ hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const Rende
     // 76.8 at 60; every larger scene is slower above 44: first_scene 120 -> 154 at 56, final_scene 562 -> 657).
     // (a stream read from global memory: mesh_scene 314 ms at 40, 308-309 at 28 ... 36)
     a.shade_t = sc.n_units <= 64 ? 56 : (sc.lds_units != sc.n_units ? 32 : RT_SHADE_T);
-    if (const char *e = std::getenv("RT_AMD_SHADE_T")) a.shade_t = std::atoi(e); // development knob
+    if (const char *e = dev_knob("RT_AMD_SHADE_T")) a.shade_t = std::atoi(e); // development knob
     for (int k = 0; k <= RT_MAX_SCHED_CHUNKS; k++) a.chunk_start[k] = rl.chunk_start[k];
     if (rl.chunk_size == 0 && (rl.n_chunks < 1 || rl.n_chunks > RT_MAX_SCHED_CHUNKS)) return hipErrorInvalidValue;
     a.tiles_x = (cam.W + 7) / 8;
@@ -52,24 +52,6 @@ hipError_t launch_render(const SceneT<R> &sc, const CameraT<R> &cam, const Rende
     // (the kernels that can walk a constant_medium's boundary sub-stream are separate instantiations: that walk keeps a
     // second traversal state alive, which the common scenes' kernels should not pay for in registers)
     const bool all = sc.lds_units == sc.n_units, tab = sc.tab_in_lds != 0;
-#if RT_QUEUES
-    if constexpr (sizeof(R) == 4) { // experimental: rays regrouped across the waves of a workgroup (rt_kernel_q.h)
-        if (cam.max_depth >= (1 << 22)) return hipErrorInvalidValue; // the bounce shares a word with the accumulator address
-        if (sc.has_gen_medium) {
-            if (all && tab) e = go(render_kernel_q<true, true, true, C::block>);
-            else if (all) e = go(render_kernel_q<true, false, true, C::block>);
-            else if (tab) e = go(render_kernel_q<false, true, true, C::block>);
-            else e = go(render_kernel_q<false, false, true, C::block>);
-        } else {
-            if (all && tab) e = go(render_kernel_q<true, true, false, C::block>);
-            else if (all) e = go(render_kernel_q<true, false, false, C::block>);
-            else if (tab) e = go(render_kernel_q<false, true, false, C::block>);
-            else e = go(render_kernel_q<false, false, false, C::block>);
-        }
-        if (e != hipSuccess) return e;
-        return hipGetLastError();
-    }
-#endif
     if (sc.has_gen_medium) {
         if (all && tab) e = go(render_kernel<R, true, true, true, C::block>);
         else if (all) e = go(render_kernel<R, true, false, true, C::block>);

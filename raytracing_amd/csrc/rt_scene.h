@@ -37,9 +37,19 @@
 #define RT_SCENE_H
 
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace rtamd {
+
+// Development knobs (hierarchy-build settings, scheduling constants, layout limits that tools/ sweeps through the
+// environment) exist only in a library built with -DRT_DEV_KNOBS (`make variant`, `make prof`); the shipped library never
+// reads the environment.
+#ifdef RT_DEV_KNOBS
+inline const char *dev_knob(const char *name) { return getenv(name); }
+#else
+inline const char *dev_knob(const char *) { return nullptr; }
+#endif
 
 // Record kinds.  0..3 are the kinds that have a code block of their own in the render kernel's wave machine, >= 4 share
 // the "other" block; K_READY is the header of the end-of-stream sentinel (traversal finished: shade), K_IDLE never
@@ -208,20 +218,8 @@ template <class R> struct SceneT { // device pointers; passed to kernels by valu
 //                              of the adds; f64 kernels: double), then the wave's item state (4 ints per slot + 16 + the
 //                              slots' NaN flags)
 //   [stream_off, ...)          the record stream (when it fits: whole or not at all), then (when they fit) the shading tables
-// RT_QUEUES (experimental float render kernel, rt_kernel_q.h): finished rays and new rays travel between the waves of a
-// workgroup through two ring buffers in LDS, in front of the stream; eight accumulator slots per wave make room for them.
-#ifndef RT_QUEUES
-#define RT_QUEUES 0
-#endif
-#ifndef RT_QCAP // entries per ring (a power of two)
-#define RT_QCAP 256
-#endif
 #ifndef RT_ITEM_SLOTS
-#if RT_QUEUES
-#define RT_ITEM_SLOTS 8
-#else
 #define RT_ITEM_SLOTS 16
-#endif
 #endif
 #ifndef RT_TILE_H // an item's pixel tile is 8 wide and RT_TILE_H (8, 4, 2 or 1) high
 #define RT_TILE_H 1
@@ -237,17 +235,12 @@ template <class R> struct LdsLayout {
     static constexpr int slot_acc = tile_px * 3;                               // accumulator cells per slot
     static constexpr int wave_acc = item_slots * slot_acc;                     // accumulator cells per wave
     static constexpr int nan_words = (slot_acc + 31) / 32;                     // per slot: one "a NaN sample was added" bit per cell
-    static constexpr int state_ints = 4 * item_slots + 16 + nan_words * item_slots + (RT_QUEUES ? item_slots : 0); // per slot: i0, j0, chunk, valid; the current item; NaN bits; paths in flight (RT_QUEUES)
+    static constexpr int state_ints = 4 * item_slots + 16 + nan_words * item_slots; // per slot: i0, j0, chunk, valid; the current item; NaN bits
     static constexpr int wave_stride = wave_acc * 8 + state_ints * 4;          // bytes per wave
     static_assert((tile_h == 8 || tile_h == 4 || tile_h == 2 || tile_h == 1) && item_slots >= 2 && item_slots <= 16, "tile / slot geometry");
     static_assert(wave_stride % 8 == 0, "accumulator cells are 8-byte aligned");
     static constexpr int wave_off = 0;
-    // RT_QUEUES, float kernels: two rings of q_fields x RT_QCAP dwords (field-major) + 16 control words
-    static constexpr int q_fields = 14;
-    static constexpr int q_ring_bytes = q_fields * RT_QCAP * 4;
-    static constexpr int queue_off = wave_off + waves * wave_stride;
-    static constexpr int queue_bytes = (RT_QUEUES && sizeof(R) == 4) ? 2 * q_ring_bytes + 64 : 0;
-    static constexpr int stream_off = queue_off + queue_bytes;
+    static constexpr int stream_off = wave_off + waves * wave_stride;
     static constexpr int total_bytes = sizeof(R) == 4 ? 160 * 1024 - 512 : 160 * 1024 - 512 - 16 * 1024;
     static constexpr int scene_bytes = total_bytes - stream_off;               // stream + tables
     static_assert(stream_off % 16 == 0 && stream_off < 65536 - 64, "ds_read immediate offset");

@@ -63,9 +63,9 @@ def load() -> C.CDLL:
     L.rt_scene_info.restype = C.c_int
     L.rt_scene_info.argtypes = [vp, vp]
     L.rt_scene_flatten_info.restype = C.c_int
-    L.rt_scene_flatten_info.argtypes = [C.POINTER(abi.SceneDesc), vp]
+    L.rt_scene_flatten_info.argtypes = [C.POINTER(abi.SceneDesc), C.c_int, vp]
     L.rt_scene_flatten_stream.restype = C.c_int
-    L.rt_scene_flatten_stream.argtypes = [C.POINTER(abi.SceneDesc), vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.rt_scene_flatten_stream.argtypes = [C.POINTER(abi.SceneDesc), C.c_int, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.rt_trace_batch.restype = C.c_int
     L.rt_trace_batch.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, C.c_int]
     L.rt_render_device.restype = C.c_int
@@ -83,30 +83,31 @@ def load() -> C.CDLL:
     return L
 
 
-def flatten_info(scene: abi.Scene) -> dict:
-    """Host-only: what rt_scene_upload would build for `scene` (raises RtError with the status it would return)."""
+def flatten_info(scene: abi.Scene, reference_order: bool = False) -> dict:
+    """Host-only: what rt_scene_upload would build for `scene` (raises RtError with the status it would return).
+    reference_order: the f32 stream with the reference's own bvh_nodes and visiting order (structure tests)."""
     L = load()
     d = scene.desc()
     out = np.zeros(5, dtype=np.int32)
-    rc = L.rt_scene_flatten_info(C.byref(d), out.ctypes.data)
+    rc = L.rt_scene_flatten_info(C.byref(d), int(reference_order), out.ctypes.data)
     if rc != abi.RT_OK:
         raise RtError(f"rt_scene_flatten_info failed with status {rc}")
     return {"f32_units": int(out[0]), "f64_units": int(out[1]), "fused_boxes": int(out[2]), "lights": int(out[3]),
             "baked_instances": int(out[4])}
 
 
-def flatten_stream(scene: abi.Scene):
+def flatten_stream(scene: abi.Scene, reference_order: bool = False):
     """Host-only: the f32 record stream rt_scene_upload would build, as (units, node_ids): a (n, 4) uint32 array of
     16-byte units (layout: csrc/rt_scene.h) and the description node id of the record starting at each unit (-1: none)."""
     L = load()
     d = scene.desc()
     n = C.c_size_t(0)
-    rc = L.rt_scene_flatten_stream(C.byref(d), None, None, 0, C.byref(n))
+    rc = L.rt_scene_flatten_stream(C.byref(d), int(reference_order), None, None, 0, C.byref(n))
     if rc != abi.RT_OK:
         raise RtError(f"rt_scene_flatten_stream failed with status {rc}")
     units = np.zeros((n.value, 4), dtype=np.uint32)
     ids = np.zeros(n.value, dtype=np.int32)
-    rc = L.rt_scene_flatten_stream(C.byref(d), units.ctypes.data, ids.ctypes.data, n.value, C.byref(n))
+    rc = L.rt_scene_flatten_stream(C.byref(d), int(reference_order), units.ctypes.data, ids.ctypes.data, n.value, C.byref(n))
     if rc != abi.RT_OK:
         raise RtError(f"rt_scene_flatten_stream failed with status {rc}")
     return units, ids

@@ -95,7 +95,7 @@ def test_split_range_properties():
     assert sorted(sum((distributed.frame_shards(124, 8, r) for r in range(8)), [])) == list(range(124))
 
 
-def test_flattener_stream_sizes_and_box_fusion(monkeypatch):
+def test_flattener_stream_sizes_and_box_fusion():
     """Host-only run of the flattener (rt_scene_flatten_info): the f32 stream fuses every box() list of six axis-aligned
     quads (quad.h:103) into one AABOX record, the f64 parity stream keeps the reference's quads; malformed graphs are
     refused with a status instead of a crash."""
@@ -106,12 +106,10 @@ def test_flattener_stream_sizes_and_box_fusion(monkeypatch):
     for n in (1, 2, 3, 4):
         assert info[n]["f32_units"] <= info[n]["f64_units"]
     assert [info[n]["baked_instances"] for n in (1, 2, 3, 4)] == [0, 0, 1, 1]  # cornell's instance is a box of quads (kept: one AABOX in its own frame); mesh: the bunny
-    # with the reference's own nodes and order (development knob) the two streams differ by exactly the fused and baked
+    # with the reference's own nodes and order (reference_order) the two streams differ by exactly the fused and baked
     # records: six 5-unit quads -> one 2-unit record; the translate(rotate_y(1000 spheres)) instance (cpuRenderer.cpp:369-375)
     # is emitted in world space in the f32 stream: no XF_ENTER / XF_EXIT pair for either transform
-    monkeypatch.setenv("RT_AMD_REF_ORDER", "1")
-    ref = {n: lib.flatten_info(fx.scene(n)) for n in (1, 3)}
-    monkeypatch.delenv("RT_AMD_REF_ORDER")
+    ref = {n: lib.flatten_info(fx.scene(n), reference_order=True) for n in (1, 3)}
     # (+ 3: the ceiling light, an axis-aligned quad, is a flat 2-unit AABOX record in the f32 stream)
     assert ref[3]["f64_units"] - ref[3]["f32_units"] == 400 * (6 * 5 - 2) + 4 * 2 + 3
     assert ref[1]["f32_units"] == ref[1]["f64_units"]
@@ -151,7 +149,7 @@ def test_flattener_refuses_cyclic_graphs():
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 6, "random 1", "random 2", "random 3"])
-def test_own_hierarchy_holds_the_reference_leaves(monkeypatch, n):
+def test_own_hierarchy_holds_the_reference_leaves(n):
     """The f32 stream's BOX records are a hierarchy of the flattener's own (surface-area heuristic over all primitives of a
     frame), not the reference's bvh_nodes.  Host-only structure check: the same leaf records as the stream in the
     reference's order (every primitive once; a medium below a span-1 bvh_node twice), every skip link forward, on a record
@@ -162,9 +160,7 @@ def test_own_hierarchy_holds_the_reference_leaves(monkeypatch, n):
     else:
         sc = fx.scene(n)
     units, ids = lib.flatten_stream(sc)
-    monkeypatch.setenv("RT_AMD_REF_ORDER", "1")
-    r_units, r_ids = lib.flatten_stream(sc)
-    monkeypatch.delenv("RT_AMD_REF_ORDER")
+    r_units, r_ids = lib.flatten_stream(sc, reference_order=True)
     n_box = stream_check.check(units, ids, r_units, r_ids)
     if not isinstance(n, str):  # (the synthetic scenes are flat lists: no bvh_node at all in the reference's order)
         r_box = sum(k == 0 for _, k in stream_check.records(r_units))

@@ -1,6 +1,8 @@
 import os, sys
 sys.path.insert(0, os.getcwd())
 os.environ["RT_AMD_PROFILE_ACTIONS"] = "1"
+os.environ["RT_AMD_PROFILE_SHADE"] = "1"
+os.environ.setdefault("RT_AMD_LIB", os.path.join(os.getcwd(), "raytracing_amd", "librt_amd_prof.so"))
 from raytracing_amd import abi, lib, scenes
 name = sys.argv[1] if len(sys.argv) > 1 else "final_scene"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 100

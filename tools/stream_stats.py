@@ -1,7 +1,7 @@
 """Walk the f32 record stream on the CPU for the fixture rays of a scene (test infrastructure, double arithmetic on the
 float records): steps per ray by record kind, and the closest hit against the fixture's.  Host-only: no GPU.
 
-usage: python tools/stream_stats.py [scene number, default 3] [max rays]        (RT_AMD_REF_ORDER=1: the reference's order)
+usage: python tools/stream_stats.py [scene number, default 3] [max rays]        (REF_ORDER=1: the reference's order)
 """
 import math
 import os
@@ -143,7 +143,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     cap = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
     sc = fx.scene(n)
-    units, ids = lib.flatten_stream(sc)
+    units, ids = lib.flatten_stream(sc, reference_order=bool(os.environ.get('REF_ORDER')))
     uf = units.view(np.float32).astype(np.float64)
     ui = units.view(np.int32)
     rays, xi, hits = fx.trace(n)
