@@ -130,7 +130,7 @@ struct Ctx {
     // hierarchy of its own).  A span-1 bvh_node has left == right (bvh.h:30) and the reference hits that child twice, a
     // constant_medium below it drawing a fresh uniform each time: `dup` is the path of second visits above the current
     // node (2*dup for the first visit, 2*dup+1 for the second); only visit 0 of the primary medium takes the fifth
-    // uniform, any other visit is keyed by (node id, dup).
+    // uniform, any other visit -- like any other medium -- takes a hash of the same 24 bits keyed by (node id, dup).
     uint32_t k0 = 0, k1 = 0, pixel = 0, sample = 0, block = 0, have = 0, stream = 0;
     uint32_t buf[4];
     int bounce = 0;
@@ -144,10 +144,12 @@ struct Ctx {
     void begin_sample(uint32_t px, uint32_t s) { pixel = px; sample = s; block = 0; have = 0; stream = 0; }
     void begin_bounce(int b) { block = 0; have = 0; stream = 0x80000000u | (uint32_t)b; }
 
-    // The rejection loops (vec3.h:106 random_in_unit_disk, vec3.h:114 random_unit_vector) draw their candidates from a
-    // xorshift32 sub-sequence seeded by ONE word of the stream (a zero word seeds 0x9e3779b9): however many candidates a
-    // loop rejects, it costs the path one word, so that no lane of a wave sends the others through another generator
-    // block (19 % of final_scene's rays needed one: fog and metal scattering).
+    // vec3.h:106 random_in_unit_disk and vec3.h:114 random_unit_vector are rejection loops in the reference.  Under the
+    // counter-based generator (protocol v4) both take ONE word of the stream, which seeds a xorshift32 sub-sequence of two
+    // uniforms, and sample their distribution DIRECTLY -- the unit sphere by (z, phi), the unit disk by (sqrt(u), phi) --
+    // the same distributions as the loops' (a point uniform in the ball, normalised, is uniform on the sphere), without a
+    // loop that a wave of 64 lanes runs until its unluckiest lane accepts (protocol v3 ran the loops on the sub-sequence).
+    // std::rand / injected draws keep the reference's loops and its plain sequence.
     uint32_t sub = 0;
     bool in_sub = false;
     void sub_begin() {
@@ -189,8 +191,16 @@ struct Ctx {
             philox_stream(0u, sample, pixel, bounce == 0 ? 0u : (0x80000000u | (uint32_t)(bounce - 1)), k0, k1, o);
             return (double)(((o[0] & 255u) << 16) | ((o[1] & 255u) << 8) | (o[2] & 255u)) * (1.0 / 16777216.0);
         }
-        philox_stream((uint32_t)node_id, sample, pixel, 1u + (uint32_t)bounce + (dup << 16), k0, k1, o);
-        return o[0] * (1.0 / 4294967296.0);
+        // any other medium (or visit): the same 24 bits, hashed with the medium's node id and visit path (protocol v4:
+        // a full generator block per medium record was 3 % of final_scene's frame, for the blue sphere inside the glass one)
+        philox_stream(0u, sample, pixel, bounce == 0 ? 0u : (0x80000000u | (uint32_t)(bounce - 1)), k0, k1, o);
+        const uint32_t k24 = ((o[0] & 255u) << 16) | ((o[1] & 255u) << 8) | (o[2] & 255u);
+        return medium_hash(k24, (uint32_t)node_id, dup) * (1.0 / 4294967296.0);
+    }
+    static uint32_t medium_hash(uint32_t k24, uint32_t node_id, uint32_t dup) { // lowbias32 (Wellons) of the keyed word
+        uint32_t x = k24 ^ (node_id * 0x9E3779B9u) ^ (dup * 0x85EBCA6Bu);
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        return x;
     }
     double next(double mn, double mx) { return mn + (mx - mn) * next(); }          // utils.h:38
     int next_int(int mn, int mx) { return int(next(mn, mx + 1)); }                 // utils.h:43
@@ -205,6 +215,11 @@ struct Ctx {
 
 inline V random_in_unit_disk(Ctx &c) {
     struct Sub { Ctx &c; Sub(Ctx &c_) : c(c_) { c.sub_begin(); } ~Sub() { c.sub_end(); } } sub(c);
+    if (c.mode == RNG_PHILOX) { // direct: radius sqrt(u1), angle 2 pi u2
+        const double u1 = c.next(), u2 = c.next();
+        const double r = std::sqrt(u1), phi = 2 * pi * u2;
+        return mk(r * std::cos(phi), r * std::sin(phi), 0);
+    }
     while (true) {
 #if ORC_ARGS_RIGHT_TO_LEFT
         double y = c.next(-1, 1);
@@ -231,6 +246,11 @@ inline V random_vec(Ctx &c, double mn, double mx) { // vec3.h:55
 }
 inline V random_unit_vector(Ctx &c) { // vec3.h:114
     struct Sub { Ctx &c; Sub(Ctx &c_) : c(c_) { c.sub_begin(); } ~Sub() { c.sub_end(); } } sub(c);
+    if (c.mode == RNG_PHILOX) { // direct: z uniform in [-1, 1], angle 2 pi u2
+        const double u1 = c.next(), u2 = c.next();
+        const double z = 1 - 2 * u1, r = std::sqrt(std::fmax(0.0, 1 - z * z)), phi = 2 * pi * u2;
+        return mk(r * std::cos(phi), r * std::sin(phi), z);
+    }
     while (true) {
         V p = random_vec(c, -1, 1);
         double lensq = length_squared(p);

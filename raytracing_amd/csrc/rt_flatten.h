@@ -340,6 +340,10 @@ template <class R> class Flattener {
             o.kind = m.kind;
             o.tex = m.tex;
             o.needs_uv = tex_needs_uv(m.tex) ? 1 : 0;
+            o.noise = -1; // (the render kernel evaluates a noise texture by the whole wave: it asks the material, not the texture)
+            if ((m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_ISOTROPIC) && m.tex >= 0 && m.tex < d_.n_textures &&
+                d_.textures[m.tex].kind == RT_TEX_NOISE)
+                o.noise = d_.textures[m.tex].a;
             cvt3(m.albedo, o.albedo);
             cvt(m.fuzz, o.fuzz);
             cvt(m.ior, o.ior);

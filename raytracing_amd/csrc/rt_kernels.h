@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "../../include/rt_amd.h"
+#include <stddef.h>
 #include <type_traits>
 #include "rt_scene.h"
 
@@ -206,11 +207,12 @@ template <class R> struct Rng {
     }
     RT_DEV R next(R mn, R mx) { return mn + (mx - mn) * next(); } // utils.h:38
 };
-// keyed draw for constant_medium.h:41
-template <class R> RT_DEV R medium_draw(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, int node_id, int bounce, int dup) {
-    uint32_t o0, o1, o2, o3;
-    philox4x32((uint32_t)node_id, sample, pixel, 1u + (uint32_t)bounce + ((uint32_t)dup << 16), k0, k1, o0, o1, o2, o3);
-    return u01<R>(o0);
+// constant_medium.h:41's draw for a medium that does not take the fifth uniform itself: a hash (lowbias32) of the same 24
+// bits keyed by the medium's node id and visit path (oracle/rt_oracle.cpp Ctx::medium_hash).  `fifth` is that uniform.
+template <class R> RT_DEV R medium_draw(R fifth, int node_id, int dup) {
+    uint32_t x = (uint32_t)(fifth * R(16777216.0)) ^ ((uint32_t)node_id * 0x9E3779B9u) ^ ((uint32_t)dup * 0x85EBCA6Bu);
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return u01<R>(x);
 }
 
 // ------------------------------------------------------------------------------------------------ scene memory
@@ -963,27 +965,29 @@ template <class R> struct Onb { // onb.h:5
 
 // Draw orders below follow oracle/rt_oracle.cpp (which is pinned to the compiled reference): vec3::random(-1,1)
 // consumes z, y, x; random_in_unit_disk y, x; quad::random v then u.
-template <class R> RT_DEV V3<R> random_unit_vector(Rng<R> &g) { // vec3.h:114
+// vec3.h:114 random_unit_vector, vec3.h:106 random_in_unit_disk: rejection loops in the reference; under the counter-based
+// generator (protocol v4, oracle/rt_oracle.cpp Ctx) ONE word of the stream seeds a xorshift32 sub-sequence of two uniforms
+// and the distribution is sampled directly -- the same distribution, without a loop that all 64 lanes of a wave run
+// until the unluckiest one accepts (protocol v3 ran the loops on the sub-sequence: 75-150 instructions per shading trip).
+template <class R> RT_DEV V3<R> random_unit_vector(Rng<R> &g) {
     uint32_t s = g.sub_begin();
-    while (true) {
-        R z = Rng<R>::sub_next(s, R(-1), R(1));
-        R y = Rng<R>::sub_next(s, R(-1), R(1));
-        R x = Rng<R>::sub_next(s, R(-1), R(1));
-        V3<R> p = mk<R>(x, y, z);
-        R lensq = len2(p);
-        if (R(1e-160) < lensq && lensq <= R(1.0)) return divide<R>(p, m_sqrt(lensq));
-    }
+    const R u1 = Rng<R>::sub_next(s, R(0), R(1));
+    const R u2 = Rng<R>::sub_next(s, R(0), R(1));
+    const R z = R(1) - R(2) * u1;
+    const R r = m_sqrt(m_max(R(0), R(1) - z * z));
+    R sp, cp;
+    sincos_rev(u2, sp, cp);
+    return mk<R>(r * cp, r * sp, z);
 }
-template <> RT_DEV V3<float> random_unit_vector<float>(Rng<float> &g) {
+template <class R> RT_DEV void random_in_unit_disk(Rng<R> &g, R &x, R &y) {
     uint32_t s = g.sub_begin();
-    while (true) {
-        float z = Rng<float>::sub_next(s, -1.f, 1.f);
-        float y = Rng<float>::sub_next(s, -1.f, 1.f);
-        float x = Rng<float>::sub_next(s, -1.f, 1.f);
-        V3<float> p = mk<float>(x, y, z);
-        float lensq = len2(p);
-        if (1e-30f < lensq && lensq <= 1.0f) return scale<float>(__builtin_amdgcn_rsqf(lensq), p); // 1e-160 underflows float
-    }
+    const R u1 = Rng<R>::sub_next(s, R(0), R(1));
+    const R u2 = Rng<R>::sub_next(s, R(0), R(1));
+    const R r = m_sqrt(u1);
+    R sp, cp;
+    sincos_rev(u2, sp, cp);
+    x = r * cp;
+    y = r * sp;
 }
 
 template <class R> RT_DEV V3<R> random_cosine_direction(Rng<R> &g) { // vec3.h:142
@@ -1091,12 +1095,7 @@ template <class R> RT_DEV RayT<R> get_ray(const CameraT<R> &cam, int i, int j, i
     V3<R> origin = ld3(cam.center);
     if (cam.defocus_angle > R(0)) { // camera.h:285, vec3.h:106
         R dx, dy;
-        uint32_t s = g.sub_begin();
-        while (true) {
-            dy = Rng<R>::sub_next(s, R(-1), R(1));
-            dx = Rng<R>::sub_next(s, R(-1), R(1));
-            if (dx * dx + dy * dy + R(0) * R(0) < R(1)) break;
-        }
+        random_in_unit_disk(g, dx, dy);
         origin = ld3(cam.center) + scale<R>(dx, ld3(cam.ddu)) + scale<R>(dy, ld3(cam.ddv));
     }
     RayT<R> r;
@@ -1126,6 +1125,38 @@ template <class R> RT_DEV RayT<R> get_ray(const CameraT<R> &cam, int i, int j, i
 #define RT_SUB_END(k, mask)
 #endif
 
+// The camera's vectors are needed by the few lanes per shading trip that start a camera ray (and the background by the
+// lanes whose ray missed), yet as ordinary kernel arguments their 23 words would be live in SGPRs across the whole wave
+// loop -- the kernel is over its SGPR budget, so values spilled to VGPR lanes come back through v_readlane + s_nop pairs
+// on the vector unit.  The float kernels therefore re-read them from the kernel-argument segment AT USE: two scalar
+// loads (scalar cache hits) into registers that live for one block.  KA_CAM = byte offset of cam_arg in that segment.
+#ifndef RT_CAM_AT_USE
+#define RT_CAM_AT_USE 1
+#endif
+typedef float rt_f16 __attribute__((ext_vector_type(16)));
+template <int OFF> RT_DEV void kernarg_load_camera(CameraT<float> &c) {
+    static_assert(offsetof(CameraT<float>, recip_sqrt_spp) == 16 && offsetof(CameraT<float>, ddv) == 84 && sizeof(CameraT<float>) == 108, "camera layout");
+    rt_f16 a;
+    rt_f4 b;
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx4 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b)
+                 : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(OFF + 16), "i"(OFF + 80)
+                 : "memory");
+    c.recip_sqrt_spp = a[0]; c.defocus_angle = a[1];
+    c.center[0] = a[2]; c.center[1] = a[3]; c.center[2] = a[4];
+    c.pixel00[0] = a[5]; c.pixel00[1] = a[6]; c.pixel00[2] = a[7];
+    c.du[0] = a[8]; c.du[1] = a[9]; c.du[2] = a[10];
+    c.dv[0] = a[11]; c.dv[1] = a[12]; c.dv[2] = a[13];
+    c.ddu[0] = a[14]; c.ddu[1] = a[15]; c.ddu[2] = b[0];
+    c.ddv[0] = b[1]; c.ddv[1] = b[2]; c.ddv[2] = b[3];
+}
+template <int OFF> RT_DEV V3<float> kernarg_load_background() {
+    static_assert(offsetof(CameraT<float>, background) == 96, "camera layout");
+    rt_f4 b;
+    asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(b) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(OFF + 92) : "memory");
+    return mk<float>(b[1], b[2], b[3]);
+}
+
 #ifdef RT_PROFILE_SHADE
 // stages of the shading trip: cycles and lanes of hit records / dealing / noise / generator / camera rays / scatter / trav_begin
 #define RT_SH_BEGIN()                                                                                                  \
@@ -1151,10 +1182,10 @@ template <class R> RT_DEV RayT<R> get_ray(const CameraT<R> &cam, int i, int j, i
 // every hit that scatters emits nothing (material.h:28-31), so the recursion's sum of emissions has exactly one non-zero
 // term, beta * (emitted | background), which is L).
 template <class R, bool ALL_LDS, class SC>
-RT_DEV bool shade_hit(const Mem<R, ALL_LDS> &mem, const SC &sc, const CameraT<R> &cam, const RayT<R> &ray, R best_t, int best_off,
+RT_DEV bool shade_hit(const Mem<R, ALL_LDS> &mem, const SC &sc, const V3<R> &background, const RayT<R> &ray, R best_t, int best_off,
                       const V3<R> &beta, V3<R> &L, Hit<R> &h) {
     if (best_off < 0) { // camera.h:300
-        L = beta * ld3(cam.background);
+        L = beta * background;
         return false;
     }
     h = finalize(mem, sc, ray, best_t, best_off, false);
@@ -1334,10 +1365,15 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
 #define RT_OWN(x) asm volatile("" : "+s"(x))
     RT_OWN(sc.cold); RT_OWN(sc.image_bytes); RT_OWN(sc.tab); RT_OWN(sc.o_xforms); RT_OWN(sc.o_mats); RT_OWN(sc.o_texs);
     RT_OWN(sc.o_images); RT_OWN(sc.o_perlins); RT_OWN(sc.o_lights); RT_OWN(sc.n_lights); RT_OWN(sc.lights_is_list);
-    RT_OWN(cam.W); RT_OWN(cam.H); RT_OWN(cam.sqrt_spp); RT_OWN(cam.max_depth); RT_OWN(cam.recip_sqrt_spp); RT_OWN(cam.defocus_angle);
-    for (int k = 0; k < 3; k++) {
-        RT_OWN(cam.center[k]); RT_OWN(cam.pixel00[k]); RT_OWN(cam.du[k]); RT_OWN(cam.dv[k]); RT_OWN(cam.ddu[k]); RT_OWN(cam.ddv[k]);
-        RT_OWN(cam.background[k]);
+    RT_OWN(cam.W); RT_OWN(cam.H); RT_OWN(cam.sqrt_spp); RT_OWN(cam.max_depth);
+    constexpr bool cam_at_use = sizeof(R) == 4 && RT_CAM_AT_USE; // (see kernarg_load_camera)
+    constexpr int KA_CAM = (int)((sizeof(SceneT<R>) + alignof(CameraT<R>) - 1) / alignof(CameraT<R>) * alignof(CameraT<R>));
+    if constexpr (!cam_at_use) {
+        RT_OWN(cam.recip_sqrt_spp); RT_OWN(cam.defocus_angle);
+        for (int k = 0; k < 3; k++) {
+            RT_OWN(cam.center[k]); RT_OWN(cam.pixel00[k]); RT_OWN(cam.du[k]); RT_OWN(cam.dv[k]); RT_OWN(cam.ddu[k]); RT_OWN(cam.ddv[k]);
+            RT_OWN(cam.background[k]);
+        }
     }
 #undef RT_OWN
     const Mem<R, ALL_LDS> mem{sc_arg.stream, sc_arg.lds_units * Pos<R>::unit};
@@ -1484,7 +1520,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     if (is_med) {
                         auto mxi = [&](int node_id, int sel) {
                             R x = med_xi;
-                            if (sel != 1) x = medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce, sel >> 1);
+                            if (sel != 1) x = medium_draw<R>(med_xi, node_id, sel >> 1);
                             return x;
                         };
                         R t;
@@ -1502,7 +1538,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     if (is_oth) {
                         auto mxi = [&](int node_id, int sel) {
                             R x = med_xi;
-                            if (sel != 1) x = medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce, sel >> 1);
+                            if (sel != 1) x = medium_draw<R>(med_xi, node_id, sel >> 1);
                             return x;
                         };
                         trav_leaf_step<GEN_MEDIUM>(mem, sc, tv, ray, tmin, mxi);
@@ -1586,8 +1622,10 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         ray.o = tv.o;
                         ray.d = tv.d;
                     }
-                    V3<R> L;
-                    scatter = shade_hit(mem, sc, cam, ray, tv.best_t, tv.best_off, beta, L, h);
+                    V3<R> L, background;
+                    if constexpr (cam_at_use) background = kernarg_load_background<KA_CAM>();
+                    else background = ld3(cam.background);
+                    scatter = shade_hit(mem, sc, background, ray, tv.best_t, tv.best_off, beta, L, h);
                     if (!scatter) add_sample(L);
                 }
                 RT_SH_END(0, ready);
@@ -1673,14 +1711,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                 bool has_turb = false;
                 R turb = R(0);
                 if constexpr (sizeof(R) == 4 && RT_WAVE_NOISE) {
-                    int noise_idx = -1;
-                    if (scatter) {
-                        const MatT<R> m = sc.mat(h.mat);
-                        if (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_ISOTROPIC) {
-                            const TexT<R> t = sc.tex(m.tex);
-                            if (t.kind == RT_TEX_NOISE) noise_idx = t.a;
-                        }
-                    }
+                    const int noise_idx = scatter ? sc.mat(h.mat).noise : -1; // (one word of the material the hit record named)
                     unsigned long long mn = lane_mask(noise_idx >= 0);
                     while (mn) { // wave-uniform
                         const int src = __builtin_ctzll(mn);
@@ -1700,15 +1731,20 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     Rng<R> g;
                     g.k0 = a.k0;
                     g.k1 = a.k1;
+                    // (the key schedule is uniform and loop-invariant: hoisted, its fourteen words are spilled to VGPR lanes and
+                    // come back as v_readlane + s_nop pairs on the vector unit; as values of THIS trip they are s_add on the scalar unit)
+                    asm volatile("" : "+s"(g.k0), "+s"(g.k1));
                     g.begin_stream(pixel, (uint32_t)smp, fresh ? 0u : (0x80000000u | (uint32_t)bounce));
                     med_xi = g.fifth(); // for the ray that starts now
                     RT_SH_END(3, true);
                     if (fresh) {
-                        int sj = (int)((float)smp * (float)cam.recip_sqrt_spp); // s / sqrt_spp, s % sqrt_spp without an integer division
+                        CameraT<R> camr = cam;
+                        if constexpr (cam_at_use) kernarg_load_camera<KA_CAM>(camr);
+                        int sj = (int)((float)smp * (float)camr.recip_sqrt_spp); // s / sqrt_spp, s % sqrt_spp without an integer division
                         int si = smp - sj * cam.sqrt_spp;
                         if (si < 0) { sj--; si += cam.sqrt_spp; }
                         if (si >= cam.sqrt_spp) { sj++; si -= cam.sqrt_spp; }
-                        ray = get_ray(cam, fi, fj, si, sj, g);
+                        ray = get_ray(camr, fi, fj, si, sj, g);
                         beta = mk<R>(R(1), R(1), R(1));
                         RT_SH_END(4, true);
                     } else {
@@ -1734,7 +1770,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                             if ((tv.hdr & 15) == K_MEDIUM) {
                                 auto mxi = [&](int node_id, int sel) {
                                     R x = med_xi;
-                                    if (sel != 1) x = medium_draw<R>(a.k0, a.k1, pixel, (uint32_t)smp, node_id, bounce, sel >> 1);
+                                    if (sel != 1) x = medium_draw<R>(med_xi, node_id, sel >> 1);
                                     return x;
                                 };
                                 R t;

@@ -126,7 +126,7 @@ template <class R> struct alignas(16) MatT {
     int32_t kind;
     int32_t tex;
     int32_t needs_uv; // texture graph contains an image texture
-    int32_t pad_;
+    int32_t noise;    // lambertian / isotropic whose texture is a noise_texture: index of its perlin table, else -1
     R albedo[3];
     R fuzz;
     R ior;
