@@ -8,7 +8,11 @@ Total work is fixed as N grows -> "scaling": "strong".  value = samples of the f
 
 `python bench.py --gpus N` with N > 1 and no RANK in the environment starts the N ranks itself (torch.distributed.run,
 fresh child processes, before this process touches a GPU) and relays rank 0's JSON line; under torchrun it is a rank.
-`--config` picks one of BASELINE.json's configurations (default: the headline one).
+`--config` picks one of BASELINE.json's configurations (default: the headline one).  `--config anim` is C5 as BASELINE
+states it: all three sequences of first_scene at 1080p -- 62 rotate + zoom frames, 42 translate frames, 20 frames of the
+bouncing spheres (scene rebuilt and re-uploaded per frame) -- frames sharded f mod N, no collective.
+`--force-collective` makes a ONE-rank run initialise the process group and go through the RCCL reduce / all_reduce / barrier
+calls of the N-rank path (tests/test_gpu_multi.py drives it on the one-GPU box).
 """
 import argparse
 import json
@@ -33,7 +37,7 @@ CONFIGS = {
                  flops=27 * 100.0 + 30 * 1.2 + 55 * 12.7 + 52 * 11.0 + 120 * 2.59),
     "first": dict(scene="first_scene", scene_id=1, width=400, height=225, spp=10, depth=50,
                   flops=27 * 393.4 + 30 * 65.9 + 55 * 0 + 52 * 0 + 120 * 20.05),
-    # C5: the rotate + zoom sequence of camera::render_animation (62 frames), frames sharded over the ranks, no collective
+    # C5: the three animation sequences (camera.h:46-154, cpuRenderer.cpp:19-84, 447-451), frames sharded over the ranks, no collective
     "anim": dict(scene="first_scene", scene_id=1, width=1920, height=1080, spp=100, depth=50,
                  flops=27 * 393.4 + 30 * 65.9 + 55 * 0 + 52 * 0 + 120 * 20.05),
 }
@@ -52,6 +56,8 @@ def parse_args(argv=None):
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end run of the C++ drop-in (rtamd_render)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="one rank: still create the process group and run the N-rank path's collectives (rehearsal of the RCCL branch)")
     return ap.parse_args(argv)
 
 
@@ -120,6 +126,24 @@ def profiled_hbm_traffic():
     return None, None
 
 
+def partial_frame_bytes(W, H, n_strata):
+    """Algorithmic HBM bytes of one render_kernel launch: the sample range is cut into chunks (rt_abi.cpp plan_render: each
+    takes a third of what is left, minimum 32 -- a half / 16 below 360 strata) and every chunk writes a partial frame of
+    64-bit cells (the reduce kernel then reads them once and writes the float frame: as many bytes again + 12 B/pixel)."""
+    if n_strata <= 0:
+        return 0
+    min_chunk, divisor = (32, 3) if n_strata >= 360 else (16, 2)
+    chunks, left = 0, n_strata
+    while left > 0:
+        take = max(left // divisor, min_chunk)
+        if take > left or left - take < min_chunk // 2:
+            take = left
+        left -= take
+        chunks += 1
+    cells = W * H * 3
+    return cells * 4 if chunks == 1 else chunks * cells * 8
+
+
 def e2e_dropin(cfg, W, H, spp, depth, n_gpus, devices=None):
     """The C++ drop-in timed end to end, as the reference times itself (cpuRenderer.cpp:446-467: scene build + render +
     PPM write): `rtamd_render <scene> <spp> <depth> false 0 true true 8 <W> <H> [--gpus N]` as a child process."""
@@ -171,12 +195,8 @@ def main():
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(a, argv))
 
-    import numpy as np
     import torch
     import torch.distributed as dist
-
-    from raytracing_amd import abi, animation, lib, scenes
-    from raytracing_amd.distributed import reduce_accum, split_range
 
     cfg = CONFIGS[a.config]
     W, H = a.width or cfg["width"], a.height or cfg["height"]
@@ -192,20 +212,48 @@ def main():
     device = dev_map[local_rank] if dev_map else local_rank
     shared_devices = bool(dev_map) and len(set(dev_map[:world])) < min(world, len(dev_map))
     backend = "gloo" if shared_devices else "nccl"
-    if world > 1:
+    grouped = world > 1 or a.force_collective  # the process group exists and every collective of the N-rank path runs
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:  # (--force-collective outside torchrun)
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(device)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group("gloo")
         world = dist.get_world_size()
+        rank = dist.get_rank()
     if a.gpus != world and rank == 0:
         print(f"bench.py: --gpus {a.gpus} but the process group has {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
     torch.cuda.set_device(device)
     dev = torch.device("cuda", device)
+    out = run_rank(a, cfg, W, H, spp, depth, rank, world, dev, device, backend, grouped, dist if grouped else None,
+                   dev_map[:world] if shared_devices else None)
+    if rank == 0 and out is not None:
+        print(json.dumps(out), flush=True)
+    if grouped:
+        dist.barrier()
+        dist.destroy_process_group()
 
+
+def run_rank(a, cfg, W, H, spp, depth, rank, world, dev, device, backend, grouped, dist, rehearsal_devices):
+    """One rank of the benchmark (the whole of it at N = 1).  `dist` is torch.distributed when the process group exists
+    (world > 1, or --force-collective), else None; rank 0 returns the JSON line as a dict."""
+    import numpy as np
+    import torch
+
+    from raytracing_amd import abi, animation, lib, scenes
+    from raytracing_amd.distributed import frame_shards, reduce_accum, split_range
+
+    anim = a.config == "anim"
     t_b0 = time.perf_counter()
-    scene = scenes.build(cfg["scene"], W, H, spp, depth, animation=0 if a.config == "anim" else None)  # C++ scene API: BVH built on the host
+    scene = scenes.build(cfg["scene"], W, H, spp, depth)  # C++ scene API: BVH built on the host
     host_build_ms = (time.perf_counter() - t_b0) * 1e3
     cam = scene.camera
     n = int(cam["sqrt_spp"][0])
@@ -213,26 +261,29 @@ def main():
     t_u0 = time.perf_counter()
     ds = ctx.upload(scene)
     flatten_upload_ms = (time.perf_counter() - t_u0) * 1e3
-    # the same upload with the hierarchy built on the device (rt_scene_upload_device_build): a reported figure, the timed
-    # frames below use the host-built stream.  None: the scene has leaves of more than one record (the device build says so)
-    device_build_ms = None
-    if rank == 0:
-        try:
-            for _ in range(2):  # (the first call also loads the build kernels' code object)
-                t_d0 = time.perf_counter()
-                ds_dev = ctx.upload(scene, device_build=True)
-                dt_d = (time.perf_counter() - t_d0) * 1e3
-                device_build_ms = dt_d if device_build_ms is None else min(device_build_ms, dt_d)
-                ds_dev.close()
-        except lib.RtError:
-            pass
     accum = torch.empty(H * W * 3, dtype=torch.float32, device=dev)
     rgb = torch.empty(H * W * 3, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
 
+    def max_over_ranks(vals):
+        """MAX over the ranks of a list of floats (RCCL on device tensors; the gloo rehearsal on host tensors)."""
+        t = torch.tensor(vals, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if grouped:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t.cpu()]
+
+    def sum_over_ranks(val):
+        t = torch.tensor([float(val)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if grouped:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.cpu()[0])
+
     def exchange():
-        if world == 1:
+        """The one exchange step of a frame: the ranks' float sums onto rank 0.  RCCL runs it on torch's
+        current stream -- the stream the render kernel was enqueued on -- so it is ordered behind the kernel without a
+        host synchronisation."""
+        if not grouped:
             return
         if backend == "nccl":
             reduce_accum(accum, dst=0)
@@ -242,24 +293,57 @@ def main():
             if rank == 0:
                 accum.copy_(host)
 
-    if a.config == "anim":
-        # frames are independent: frame f -> rank f mod world, nothing is exchanged
-        cams = [scene.animation[f:f + 1] for f in animation.frame_shards(len(scene.animation), world, rank)]
-        n_frames_total = len(scene.animation)
+    extra = {}
+    if anim:
+        # C5: frame f of each sequence -> rank f mod world, nothing is exchanged.  The camera sequences (rotate
+        # + zoom, translate) move through ONE uploaded scene; every bounce frame builds, uploads and frees its own scene
+        # inside the timed region (cpuRenderer.cpp:447-451 rebuilds it per frame too).
+        seqs = {}
+        for method, label in ((0, "rotate_zoom"), (1, "translate")):
+            sc_m = scenes.build(cfg["scene"], W, H, spp, depth, animation=method)
+            seqs[label] = (ctx.upload(sc_m), [sc_m.animation[f:f + 1] for f in frame_shards(len(sc_m.animation), world, rank)],
+                           len(sc_m.animation))
+        bounce_frames = frame_shards(animation.N_BOUNCE_FRAMES, world, rank)
+        n_frames_total = sum(v[2] for v in seqs.values()) + animation.N_BOUNCE_FRAMES
         s0, s1 = 0, n * n
         units_per_step = n_frames_total
+        seq_ms = {"rotate_zoom": [], "translate": [], "bounce": []}
+        bounce_host_ms = []
+        seq_ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in seq_ms}
 
         def frame(k=None):
             if k is not None:
                 ev[k][0].record()
-            for c in cams:
-                ds.render_device(c, accum.data_ptr(), seed=1984, precision=abi.RT_PREC_F32, stream=stream)
-                ds.tonemap_device(accum.data_ptr(), 1.0 / (n * n), H * W, rgb.data_ptr(), stream=stream)
+            for label, (ds_m, cams_m, _) in seqs.items():
+                seq_ev[label][0].record()
+                for c in cams_m:
+                    ds_m.render_device(c, accum.data_ptr(), seed=1984, precision=abi.RT_PREC_F32, stream=stream)
+                    ds_m.tonemap_device(accum.data_ptr(), 1.0 / (n * n), H * W, rgb.data_ptr(), stream=stream)
+                seq_ev[label][1].record()
+            seq_ev["bounce"][0].record()
+            host_ms = 0.0
+            for f in bounce_frames:
+                t_h = time.perf_counter()
+                sc_f = scenes.build("first_scene_moving", W, H, spp, depth, frame=f)
+                try:
+                    ds_f = ctx.upload(sc_f, device_build=True)  # hierarchy built on the GPU
+                except lib.RtError:
+                    ds_f = ctx.upload(sc_f)
+                host_ms += (time.perf_counter() - t_h) * 1e3
+                ds_f.render_device(sc_f.camera, accum.data_ptr(), seed=1984, precision=abi.RT_PREC_F32, stream=stream)
+                ds_f.tonemap_device(accum.data_ptr(), 1.0 / (n * n), H * W, rgb.data_ptr(), stream=stream)
+                torch.cuda.current_stream().synchronize()  # (the scene is freed below: its frame must have finished)
+                ds_f.close()
+            seq_ev["bounce"][1].record()
             if k is not None:
                 ev[k][1].record()
-        launches_per_step = max(len(cams), 1)
+                torch.cuda.current_stream().synchronize()
+                for label in seq_ms:
+                    seq_ms[label].append(seq_ev[label][0].elapsed_time(seq_ev[label][1]))
+                bounce_host_ms.append(host_ms)
+        my_frames = sum(len(v[1]) for v in seqs.values()) + len(bounce_frames)
+        launches_per_step = max(my_frames, 1)
     else:
-        cams = [cam]
         s0, s1 = split_range(n * n, world, rank)
         units_per_step = 1
 
@@ -276,82 +360,121 @@ def main():
 
     for _ in range(a.warmup):
         frame()
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(a.steps):
         frame(k)
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     dt = time.perf_counter() - t0
     # average duration of one render_kernel launch on this rank (HIP events on the stream the kernel runs on)
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) / launches_per_step if a.steps else 0.0
-    t = torch.tensor([dt, kern_ms], dtype=torch.float64, device=dev)
-    if world > 1 and backend == "nccl":
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elif world > 1:
-        th = t.cpu()
-        dist.all_reduce(th, op=dist.ReduceOp.MAX)
-        t = th
-    dt, kern_ms = float(t[0]), float(t[1])
+    if anim:  # (the events of a step also span tone mapping and, for the bounce frames, the host's scene builds)
+        kern_ms = float(np.mean([sum(seq_ms[k][i] for k in seq_ms) for i in range(a.steps)])) / launches_per_step if a.steps else 0.0
+    else:
+        kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) / launches_per_step if a.steps else 0.0
+    dt, kern_ms = max_over_ranks([dt, kern_ms])
     # rays traced per step (SURVEY 8d asks for rays/s too): one more, untimed, pass that reads the counters back
     rays_local = 0
-    for c in cams:
-        st = ds.render_device(c, accum.data_ptr(), seed=1984, s_begin=s0, s_end=s1, precision=abi.RT_PREC_F32, stream=stream,
-                              want_stats=True)
-        rays_local += int(st["rays"])
-    rays = torch.tensor([float(rays_local)], dtype=torch.float64)
-    if world > 1:
-        if backend == "nccl":
-            rays = rays.to(dev)
-        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
-    rays = float(rays[0])
+    if anim:
+        for label, (ds_m, cams_m, _) in seqs.items():
+            for c in cams_m:
+                rays_local += int(ds_m.render_device(c, accum.data_ptr(), seed=1984, precision=abi.RT_PREC_F32, stream=stream, want_stats=True)["rays"])
+        for f in bounce_frames:
+            sc_f = scenes.build("first_scene_moving", W, H, spp, depth, frame=f)
+            ds_f = ctx.upload(sc_f)
+            rays_local += int(ds_f.render_device(sc_f.camera, accum.data_ptr(), seed=1984, precision=abi.RT_PREC_F32, stream=stream, want_stats=True)["rays"])
+            ds_f.close()
+    else:
+        rays_local = int(ds.render_device(cam, accum.data_ptr(), seed=1984, s_begin=s0, s_end=s1, precision=abi.RT_PREC_F32, stream=stream,
+                                          want_stats=True)["rays"])
+    rays = sum_over_ranks(rays_local)
 
-    if rank == 0:
-        samples = W * H * n * n * units_per_step
-        sec_per_step = dt / max(a.steps, 1)
-        # dominant kernel = render_kernel<float>; per launch this rank traces (s1 - s0) strata of every pixel
-        launch_samples = W * H * (s1 - s0)
-        achieved = launch_samples * cfg["flops"] / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-        headline = a.config == "final" and (W, H, spp) == (1920, 1080, 1000)
-        traffic, traffic_src = profiled_hbm_traffic() if world == 1 and headline else (None, None)
-        if a.config == "anim":
-            workload = (f"first_scene rotate+zoom animation, {units_per_step} frames {W}x{H}, {spp} spp (-> {n * n} stratified samples), "
-                        f"depth {depth}, frames sharded over {world} GPU(s), no collective")
-            metric = "Msamples/s (node), first_scene animation 1080p"
-        else:
-            workload = (f"{cfg['scene']} {W}x{H}, {spp} spp (-> {n * n} stratified samples), depth {depth}, "
-                        f"spp range split over {world} GPU(s) + " + ("RCCL reduce" if backend == "nccl" else "gloo reduce through host memory (rehearsal: ranks share a device)"))
-            metric = f"Msamples/s (node), {cfg['scene']} {'1080p' if (W, H) == (1920, 1080) else f'{W}x{H}'} @{spp} spp"
-        out = {
-            "metric": metric, "value": round(samples / sec_per_step / 1e6, 3),
-            "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(sec_per_step * 1e3, 3), "sec_per_frame": round(sec_per_step / units_per_step, 4),
-            "grays_per_s": round(rays / sec_per_step / 1e9, 3), "rays_per_sample": round(rays / samples, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "samples_per_step": samples, "collective": None if a.config == "anim" or world == 1 else backend},
-            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 5), "traffic": traffic,
-                         "traffic_note": (f"HBM bytes per launch from the committed PMC passes ({traffic_src}); not collected live"
-                                          if traffic else "HBM counters need their own profiler passes (profiles/)"),
-                         "kernel": "render_kernel<float>", "kernel_ms": round(kern_ms, 3),
-                         "flops_per_sample": round(cfg["flops"], 1),
-                         "note": "non-MFMA FP32 vector roof (SURVEY 8d): the scene is cache-resident, HBM is not the bound"},
-            "host": {"scene_build_ms": round(host_build_ms, 2), "flatten_upload_ms": round(flatten_upload_ms, 2),
-                     "device_build_upload_ms": None if device_build_ms is None else round(device_build_ms, 2),
-                     "note": "scene function + host BVH build (C++ scene API); flattening + H2D upload of the f32 stream; "
-                             "the same upload with the hierarchy built on the device"},
-        }
-        if not a.no_e2e and a.config != "anim":
-            out["e2e"] = e2e_dropin(cfg, W, H, spp, depth, world, devices=dev_map[:world] if shared_devices else None)
-        if world == 1 and not a.no_cpu_baseline and a.config != "anim":
-            out["cpu_baseline"] = cpu_baseline(cfg["scene_id"], min(16, os.cpu_count() or 1))
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+
+    def kernel_ms_of(scene_handle, camera, **kw):
+        best = None
+        for _ in range(2):
+            st = scene_handle.render_device(camera, accum.data_ptr(), seed=1984, precision=abi.RT_PREC_F32, stream=stream, want_stats=True, **kw)
+            best = st["kernel_ms"] if best is None else min(best, st["kernel_ms"])
+        return best
+
+    # the same upload with the hierarchy built on the device (rt_scene_upload_device_build), and a frame rendered from that
+    # stream: reported figures, the timed frames above use the host-built stream.  None: the device build refuses the scene
+    device_build_ms = device_build_render_ms = None
+    try:
+        for _ in range(2):  # (the first call also loads the build kernels' code object)
+            t_d0 = time.perf_counter()
+            ds_dev = ctx.upload(scene, device_build=True)
+            dt_d = (time.perf_counter() - t_d0) * 1e3
+            device_build_ms = dt_d if device_build_ms is None else min(device_build_ms, dt_d)
+            if _ == 1 and not anim:
+                device_build_render_ms = kernel_ms_of(ds_dev, cam, s_begin=s0, s_end=s1)
+            ds_dev.close()
+    except lib.RtError:
+        pass
+    headline = a.config == "final" and (W, H, spp) == (1920, 1080, 1000)
+    if world == 1 and not anim and n * n >= 64:
+        # what each of 8 GPUs would render: one eighth of the strata of every pixel (north_star asks for the 8-GPU frame;
+        # this is its kernel on one GPU -- the gap to 1/8 of the whole frame's kernel is the end-of-kernel tail)
+        e_ms = kernel_ms_of(ds, cam, s_begin=0, s_end=(n * n) // 8)
+        extra["eighth_range_ms"] = round(e_ms, 3)
+        extra["eighth_range_vs_linear"] = round(kern_ms * ((n * n) // 8) / (n * n) / e_ms, 4) if e_ms > 0 else None
+
+    samples = W * H * n * n * units_per_step
+    sec_per_step = dt / max(a.steps, 1)
+    # dominant kernel = render_kernel<float>; per launch this rank traces (s1 - s0) strata of every pixel
+    launch_samples = W * H * (s1 - s0)
+    achieved = launch_samples * cfg["flops"] / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+    traffic, traffic_src = profiled_hbm_traffic() if world == 1 and headline else (None, None)
+    if anim:
+        workload = (f"first_scene animation, all three sequences: 62 rotate+zoom + 42 translate + 20 bounce = {units_per_step} frames {W}x{H}, "
+                    f"{spp} spp (-> {n * n} stratified samples), depth {depth}, frames sharded f mod {world} over {world} GPU(s), no collective; "
+                    "the bounce frames rebuild and re-upload their scene inside the timed region")
+        metric = "Msamples/s (node), first_scene animation 1080p"
+        extra["sequences"] = {
+            label: {"frames": {"rotate_zoom": 62, "translate": 42, "bounce": animation.N_BOUNCE_FRAMES}[label],
+                    "frames_on_rank0": len(bounce_frames) if label == "bounce" else len(seqs[label][1]),
+                    "sec_per_frame_rank0": round(float(np.mean(ms)) * 1e-3 / max(len(bounce_frames) if label == "bounce" else len(seqs[label][1]), 1), 5)}
+            for label, ms in seq_ms.items() if ms}
+        if bounce_host_ms and bounce_frames:
+            extra["sequences"]["bounce"]["host_build_upload_ms_per_frame"] = round(float(np.mean(bounce_host_ms)) / len(bounce_frames), 3)
+            extra["sequences"]["bounce"]["host_share"] = round(float(np.mean(bounce_host_ms)) / max(float(np.mean(seq_ms["bounce"])), 1e-9), 4)
+    else:
+        how = "one GPU, whole sample range, no collective" if not grouped else (
+            f"spp range split over {world} GPU(s) + " + ("one RCCL reduce onto rank 0" if backend == "nccl" else "gloo reduce through host memory (rehearsal: ranks share a device)"))
+        workload = f"{cfg['scene']} {W}x{H}, {spp} spp (-> {n * n} stratified samples), depth {depth}, {how}"
+        metric = f"Msamples/s (node), {cfg['scene']} {'1080p' if (W, H) == (1920, 1080) else f'{W}x{H}'} @{spp} spp"
+    out = {
+        "metric": metric, "value": round(samples / sec_per_step / 1e6, 3),
+        "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(sec_per_step * 1e3, 3), "sec_per_frame": round(sec_per_step / units_per_step, 4),
+        "grays_per_s": round(rays / sec_per_step / 1e9, 3), "rays_per_sample": round(rays / samples, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "samples_per_step": samples, "collective": backend if grouped and not anim else None},
+        "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 5), "traffic": traffic,
+                     "traffic_note": (f"HBM bytes per launch from the committed PMC passes ({traffic_src}); not collected live"
+                                      if traffic else "HBM counters need their own profiler passes (profiles/)"),
+                     "algorithmic_bytes": None if anim else partial_frame_bytes(W, H, s1 - s0),
+                     "kernel": "render_kernel<float>", "kernel_ms": round(kern_ms, 3),
+                     "flops_per_sample": round(cfg["flops"], 1),
+                     "note": "non-MFMA FP32 vector roof (SURVEY 8d): the scene is cache-resident, HBM is not the bound"},
+        "host": {"scene_build_ms": round(host_build_ms, 2), "flatten_upload_ms": round(flatten_upload_ms, 2),
+                 "device_build_upload_ms": None if device_build_ms is None else round(device_build_ms, 2),
+                 "device_build_render_ms": None if device_build_render_ms is None else round(device_build_render_ms, 3),
+                 "note": "scene function + host BVH build (C++ scene API); flattening + H2D upload of the f32 stream; the same "
+                         "upload with the hierarchy built on the device; render_kernel time of this rank's launch on that stream"},
+    }
+    out.update(extra)
+    if not a.no_e2e and not anim:
+        out["e2e"] = e2e_dropin(cfg, W, H, spp, depth, world, devices=rehearsal_devices)
+    if world == 1 and not a.no_cpu_baseline and not anim:
+        out["cpu_baseline"] = cpu_baseline(cfg["scene_id"], min(16, os.cpu_count() or 1))
+    return out
 
 
 if __name__ == "__main__":

@@ -305,7 +305,8 @@ int rt_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt
  * and the same scene uploaded through each (two contexts may share a device).  Context k traces strata
  * [s_begin + k*n/G, s_begin + (k+1)*n/G) of the n = s_end - s_begin requested -- the RNG is keyed by (seed, pixel, stratum),
  * so the image does not depend on G (the reference has no multi-GPU code) -- all devices run side by side, then
- * the peers' float sums are copied to ctxs[0]'s device and added in context order.  Outputs as rt_render; stats->kernel_ms
+ * the float sums are added up a fixed binary tree over the contexts (stride 1, 2, 4 ...: context k takes context k + stride's
+ * buffer by a direct peer copy over xGMI and adds it, the pairs of a level concurrently), ending on ctxs[0]'s device.  Outputs as rt_render; stats->kernel_ms
  * is the slowest device's.  Errors of any context are reported through rt_last_error(ctxs[0]). */
 int rt_render_multi(rt_ctx *const *ctxs, const rt_scene *const *scenes, int n_devices, const rt_camera *cam,
                     const rt_render_params *params, float *accum_rgb, uint8_t *rgb8, rt_stats *stats);

@@ -44,6 +44,7 @@ struct rt_ctx {
     unsigned long long *counter = nullptr;
     unsigned char *static_scratch = nullptr; // this device's copy of `scratch` (hipGetSymbolAddress in rt_init)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t xstream = nullptr; // rt_render_multi: this device's side of the exchange (created on first use)
     int n_cus = 256;
     // development knobs (environment RT_AMD_LDS_UNITS / RT_AMD_CHUNKS); -1 / 0 = library default
     int lds_limit_units = -1;
@@ -418,6 +419,8 @@ void print_profile(rt_ctx *ctx, const unsigned long long *c) { // diagnostic bui
                          nm[k], (double)c[4 + 3 * k], 100.0 * (double)c[4 + 3 * k] / (double)(c[3] ? c[3] : 1), (double)c[5 + 3 * k],
                          (double)c[4 + 3 * k] / (double)(c[5 + 3 * k] ? c[5 + 3 * k] : 1),
                          (double)c[6 + 3 * k] / (double)(c[5 + 3 * k] ? c[5 + 3 * k] : 1));
+        std::fprintf(stderr, "[rt_amd profile] box steps %.4g (%.1f per trip), lanes per step %.1f, lane-steps %.4g\n", (double)c[56],
+                     (double)c[56] / (double)(c[5] ? c[5] : 1), (double)c[57] / (double)(c[56] ? c[56] : 1), (double)c[57]);
         std::fprintf(stderr, "[rt_amd profile] per trip: %.1f lanes idle (item tail), %.1f lanes waiting for shading, of 64; %.1f%% of trips after the item's last unit was dealt\n",
                      (double)c[33] / (double)(c[35] ? c[35] : 1), (double)c[34] / (double)(c[35] ? c[35] : 1), 100.0 * (double)c[36] / (double)(c[35] ? c[35] : 1));
     }
@@ -539,6 +542,7 @@ void rt_shutdown(rt_ctx *ctx) {
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->rgb) (void)hipFree(ctx->rgb);
     if (ctx->counter) (void)hipFree(ctx->counter);
+    if (ctx->xstream) (void)hipStreamDestroy(ctx->xstream);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -805,16 +809,36 @@ int rt_render_multi(rt_ctx *const *ctxs, const rt_scene *const *scenes, int n_de
         total.rays += st.rays;
         if (st.kernel_ms > total.kernel_ms) total.kernel_ms = st.kernel_ms; // the devices run side by side
     }
-    // the exchange step: the peers' sums are added onto the root device in context order (a fixed order: the frame repeats)
+    // The exchange step: a binary tree over the contexts in a FIXED order (the frame repeats): at stride 1, 2, 4 ... context k
+    // takes the sums of context k + stride -- a direct peer copy over xGMI into its staging buffer, then one add kernel, both
+    // on its own exchange stream -- so the pairs of a level run side by side on different devices and links, and 8 GPUs
+    // take 3 levels instead of 7 copies in a row on the root.  (Every render above has finished: collect_stats waited.)
+    for (int stride = 1; stride < n_devices; stride *= 2) {
+        for (int k = 0; k + stride < n_devices; k += 2 * stride) {
+            rt_ctx *rcv = ctxs[k], *snd = ctxs[k + stride];
+            if (hipSetDevice(rcv->device) != hipSuccess) return fail_from(k, set_err(rcv, RT_ERR_HIP, "hipSetDevice failed"));
+            if (!rcv->xstream && hipStreamCreateWithFlags(&rcv->xstream, hipStreamNonBlocking) != hipSuccess)
+                return fail_from(k, set_err(rcv, RT_ERR_HIP, "hipStreamCreateWithFlags failed"));
+            if (snd->device != rcv->device) { // direct access to the peer's memory; harmless if it was enabled before
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, rcv->device, snd->device) == hipSuccess && can) {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(snd->device, 0);
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError(); // the copy below still works, staged by the runtime
+                    else (void)hipGetLastError();
+                }
+            }
+            if ((rc = ensure(rcv, (void **)&rcv->stage, &rcv->stage_bytes, bytes)) != RT_OK) return fail_from(k, rc);
+            hipError_t e = hipMemcpyPeerAsync(rcv->stage, rcv->device, snd->accum, snd->device, bytes, rcv->xstream);
+            if (e == hipSuccess) e = launch_add_into(rcv->accum, rcv->stage, n_px * 3, rcv->xstream);
+            if (e != hipSuccess) return fail_from(k, set_err(rcv, RT_ERR_HIP, std::string("rt_render_multi exchange: ") + hipGetErrorString(e)));
+        }
+        for (int k = 0; k + stride < n_devices; k += 2 * stride) { // the next level reads what this one wrote
+            rt_ctx *rcv = ctxs[k];
+            if (hipSetDevice(rcv->device) != hipSuccess || hipStreamSynchronize(rcv->xstream) != hipSuccess)
+                return fail_from(k, set_err(rcv, RT_ERR_HIP, "rt_render_multi exchange: stream synchronisation failed"));
+        }
+    }
     HIP_TRY(root, hipSetDevice(root->device));
-    if (n_devices > 1) {
-        rc = ensure(root, (void **)&root->stage, &root->stage_bytes, bytes);
-        if (rc) return rc;
-    }
-    for (int k = 1; k < n_devices; k++) {
-        HIP_TRY(root, hipMemcpyPeer(root->stage, root->device, ctxs[k]->accum, ctxs[k]->device, bytes));
-        HIP_TRY(root, launch_add_into(root->accum, root->stage, n_px * 3, nullptr));
-    }
     HIP_TRY(root, hipDeviceSynchronize());
     if (stats) *stats = total;
     return finish_to_host(root, cam, accum_rgb, rgb8);

@@ -835,7 +835,11 @@ template <class R> class Flattener {
         double axis_min = 0;            // only axes whose centroid extent is at least this share of the widest are split
         double overlap = 0.1;           // weight of the area the two sides of a split share, in the split's cost (0 -> 0.1:
                                         // final_scene 635 -> 623, cornell_box 105 -> 103, mesh_scene 477 -> 471; 1.0: 665)
+        uint32_t jitter = 0;            // != 0: seed of a randomised build (see build(): bin grid shifted per node, near-ties broken at random)
+        double jitter_eps = 0.03;       //   candidates within this share of the cheapest split count as ties
         BuildKnobs() { // development knobs
+            if (const char *e = dev_knob("RT_AMD_BVH_JITTER")) jitter = (uint32_t)std::atoll(e);
+            if (const char *e = dev_knob("RT_AMD_BVH_EPS")) jitter_eps = std::atof(e);
             if (const char *e = dev_knob("RT_AMD_BVH_T2")) thr2 = std::atof(e);
             if (const char *e = dev_knob("RT_AMD_BVH_TN")) thrn = std::atof(e);
             if (const char *e = dev_knob("RT_AMD_BVH_ORDER")) order = std::atoi(e);
@@ -879,6 +883,14 @@ template <class R> class Flattener {
             const int NB = knobs_.bins;
             double best = INFINITY;
             int best_axis = -1, best_bin = -1;
+            // randomised build (the tuner's candidates): the bin grid of this node is shifted by a random share of a bin, and
+            // among the splits within jitter_eps of the cheapest one is picked at random -- trees of the same quality by the
+            // heuristic, which the walk may like better or worse (the landscape is rough: see above)
+            uint32_t jr = knobs_.jitter ? knobs_.jitter * 0x9E3779B9u + (uint32_t)n * 0x85EBCA6Bu + (uint32_t)bdepth * 0xC2B2AE35u + (uint32_t)idx[0] : 0u;
+            auto jnext = [&]() { jr ^= jr << 13; jr ^= jr >> 17; jr ^= jr << 5; return (jr >> 8) * (1.0 / 16777216.0); };
+            const double shift = knobs_.jitter ? jnext() : 0.0; // bins cover [clo - shift * w, ...) with w = ext / (NB - 1)
+            struct Cand { double cost; int axis, bin; };
+            std::vector<Cand> cands;
             double max_ext = 0;
             for (int a = 0; a < 3; a++)
                 if (std::isfinite(chi[a] - clo[a])) max_ext = std::fmax(max_ext, chi[a] - clo[a]);
@@ -888,10 +900,10 @@ template <class R> class Flattener {
                 if (ext < knobs_.axis_min * max_ext) continue; // (a split across a thin extent stacks the two sides on one footprint)
                 struct Bin { double lo[3], hi[3]; int n; } bin[32];
                 for (int b = 0; b < NB; b++) { b_empty(bin[b].lo, bin[b].hi); bin[b].n = 0; }
-                const double sc = NB / ext;
+                const double sc = knobs_.jitter ? (NB - 1) / ext : NB / ext;
                 for (int k = 0; k < n; k++) {
                     const Leaf &l = lv[idx[k]];
-                    int b = (int)((0.5 * (l.lo[a] + l.hi[a]) - clo[a]) * sc);
+                    int b = (int)((0.5 * (l.lo[a] + l.hi[a]) - clo[a]) * sc + shift);
                     b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
                     b_grow(bin[b].lo, bin[b].hi, l.lo, l.hi);
                     bin[b].n++;
@@ -927,14 +939,23 @@ template <class R> class Flattener {
                         if (any) cost += knobs_.overlap * b_area(ol, oh) * (double)(cnt + rn[b + 1]);
                     }
                     if (cost < best) { best = cost; best_axis = a; best_bin = b; }
+                    if (knobs_.jitter) cands.push_back(Cand{cost, a, b});
                 }
+            }
+            if (knobs_.jitter && best_axis >= 0) {
+                std::vector<Cand> near;
+                for (const Cand &c : cands)
+                    if (c.cost <= best * (1.0 + knobs_.jitter_eps)) near.push_back(c);
+                const Cand &pick = near[std::min(near.size() - 1, (size_t)(jnext() * (double)near.size()))];
+                best_axis = pick.axis;
+                best_bin = pick.bin;
             }
             if (best_axis >= 0) {
                 const int a = best_axis;
-                const double sc = NB / (chi[a] - clo[a]);
+                const double sc = knobs_.jitter ? (NB - 1) / (chi[a] - clo[a]) : NB / (chi[a] - clo[a]);
                 int *mid = std::stable_partition(idx, idx + n, [&](int k) { // stable: each side keeps the reference's relative order
                     const Leaf &l = lv[k];
-                    int b = (int)((0.5 * (l.lo[a] + l.hi[a]) - clo[a]) * sc);
+                    int b = (int)((0.5 * (l.lo[a] + l.hi[a]) - clo[a]) * sc + shift);
                     b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
                     return b <= best_bin;
                 });

@@ -32,9 +32,41 @@ RT_DEV float m_sin(float x) { return sinf(x); }
 RT_DEV double m_sin(double x) { return sin(x); }
 RT_DEV float m_cos(float x) { return cosf(x); }
 RT_DEV double m_cos(double x) { return cos(x); }
-RT_DEV float m_acos(float x) { return acosf(x); }
+// acos / atan2 of the float path (sphere.h:89 get_sphere_uv is their only caller: texture coordinates of an image-textured
+// sphere).  The library routines are ~70 instructions each and run in every shading trip in which one lane hit such a
+// sphere (final_scene's globe: three trips in four); these are 13 and 18.  acos: Abramowitz & Stegun 4.4.46,
+// sqrt(1 - |x|) * P7(|x|), |error| <= 2e-8 + float rounding (2.3e-7 measured); atan2: odd minimax polynomial of degree 11
+// on [0, 1] after the usual octant reduction, |error| <= 2e-6 rad = 3e-7 of a turn -- a third of a thousandth of
+// earthmap.jpg's 1024 texels.  (The double path calls libm, as the reference does.)
+RT_DEV float m_acos(float x) {
+    const float ax = fabsf(x);
+    float p = -0.0012624911f;
+    p = fmaf(p, ax, 0.0066700901f);
+    p = fmaf(p, ax, -0.0170881256f);
+    p = fmaf(p, ax, 0.0308918810f);
+    p = fmaf(p, ax, -0.0501743046f);
+    p = fmaf(p, ax, 0.0889789874f);
+    p = fmaf(p, ax, -0.2145988016f);
+    p = fmaf(p, ax, 1.5707963050f);
+    const float r = __builtin_amdgcn_sqrtf(1.0f - ax) * p;
+    return x < 0.0f ? 3.14159265358979323846f - r : r;
+}
 RT_DEV double m_acos(double x) { return acos(x); }
-RT_DEV float m_atan2(float y, float x) { return atan2f(y, x); }
+RT_DEV float m_atan2(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float t = fminf(ax, ay) * __builtin_amdgcn_rcpf(fmaxf(fmaxf(ax, ay), 1e-30f)); // (0, 0) -> 0, as atan2f
+    const float q = t * t;
+    float p = -0.01172120f;
+    p = fmaf(p, q, 0.05265332f);
+    p = fmaf(p, q, -0.11643287f);
+    p = fmaf(p, q, 0.19354346f);
+    p = fmaf(p, q, -0.33262347f);
+    p = fmaf(p, q, 0.99997726f);
+    float r = p * t;
+    r = ay > ax ? 1.57079632679489661923f - r : r;
+    r = x < 0.0f ? 3.14159265358979323846f - r : r;
+    return y < 0.0f ? -r : r;
+}
 RT_DEV double m_atan2(double y, double x) { return atan2(y, x); }
 // v_log_f32 (log2, ~1 ulp) * ln 2: ~1e-6 relative on (0,1), enough for a free-path length.  (__logf would add a denormal
 // rescale and an extended-precision correction: ten more instructions per medium test; the argument is a 24-bit uniform.)
@@ -951,8 +983,10 @@ template <class R, class SC> RT_DEV V3<R> tex_value(const SC &sc, int tex, R u, 
 // ------------------------------------------------------------------------------------------------ sampling
 template <class R> struct Onb { // onb.h:5
     V3<R> u, v, w;
-    RT_DEV explicit Onb(V3<R> n) {
-        w = unit(n);
+    // unit_n: `n` is a hit record's normal -- unit length by construction (sphere: (p - c) / r; stored quad / triangle /
+    // box-face normals; rotations keep lengths) -- so the float path skips onb.h:8's re-normalisation (7 instructions)
+    RT_DEV explicit Onb(V3<R> n, bool unit_n = false) {
+        w = (sizeof(R) == 4 && unit_n) ? n : unit(n);
         V3<R> a = (m_abs(w.x) > R(0.9)) ? mk<R>(R(0), R(1), R(0)) : mk<R>(R(1), R(0), R(0));
         v = unit(cross(w, a));
         u = cross(w, v);
@@ -1240,15 +1274,21 @@ RT_DEV void shade_scatter(const SC &sc, RayT<R> &ray, const Hit<R> &h, V3<R> &be
     V3<R> dir;
     int picked = -1;
     if (g.next() < R(0.5)) dir = light_random(sc, h.p, g, picked);
-    else if (lambert) dir = Onb<R>(h.n).transform(random_cosine_direction(g)); // pdf.h:40
+    else if (lambert) dir = Onb<R>(h.n, true).transform(random_cosine_direction(g)); // pdf.h:40
     else dir = random_unit_vector(g);                                          // pdf.h:25
     R v0 = light_pdf(sc, h.p, dir, picked);
     R v1, spdf;
     if (lambert) {
-        R cosine_theta = dot(unit(dir), unit(h.n)); // cosine_pdf::value pdf.h:35 (onb re-normalises w)
-        v1 = m_max(R(0), m_div(cosine_theta, Const<R>::pi));
-        R cos_theta = dot(h.n, unit(dir)); // lambertian::scattering_pdf material.h:51
-        spdf = cos_theta < R(0) ? R(0) : m_div(cos_theta, Const<R>::pi);
+        if constexpr (sizeof(R) == 4) { // |h.n| = 1: the two cosines below are one number
+            const R c = dot(h.n, unit(dir)) * R(1.0 / 3.14159265358979323846);
+            v1 = m_max(R(0), c);
+            spdf = v1;
+        } else {
+            R cosine_theta = dot(unit(dir), unit(h.n)); // cosine_pdf::value pdf.h:35 (onb re-normalises w)
+            v1 = m_max(R(0), m_div(cosine_theta, Const<R>::pi));
+            R cos_theta = dot(h.n, unit(dir)); // lambertian::scattering_pdf material.h:51
+            spdf = cos_theta < R(0) ? R(0) : m_div(cos_theta, Const<R>::pi);
+        }
     } else {
         v1 = R(1) / (R(4) * Const<R>::pi);   // pdf.h:21
         spdf = R(1) / (R(4) * Const<R>::pi); // material.h:153
@@ -1389,7 +1429,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
 #ifdef RT_PROFILE_ACTIONS
     unsigned long long prof_cyc[A_COUNT] = {}, prof_trips[A_COUNT] = {}, prof_lanes[A_COUNT] = {};
     const unsigned long long t_wave0 = __builtin_amdgcn_s_memtime();
-    unsigned long long prof_idle = 0, prof_ready = 0, prof_all = 0, prof_tail = 0;
+    unsigned long long prof_idle = 0, prof_ready = 0, prof_all = 0, prof_tail = 0, prof_box_steps = 0, prof_box_lane_steps = 0;
     unsigned long long sub_cyc[A_COUNT] = {}, sub_trips[A_COUNT] = {}, sub_lanes[A_COUNT] = {};
 #endif
 #ifdef RT_PROFILE_SHADE
@@ -1417,7 +1457,15 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     int pp = 0;         //   pixel within the tile | accumulator slot << 6,
     uint32_t pixel = 0; //   pixel within the image (row-major)
     auto wsl = [&](int k) { return __builtin_amdgcn_readfirstlane(ws[k]); };
-    int units_left = 0; // of the current item; -1: the item cursor is exhausted (wave-uniform, the only item state in a register)
+    int units_left = 0; // of the current item; -1: the item cursor is exhausted (wave-uniform)
+#ifndef RT_DEAL_SGPR
+#define RT_DEAL_SGPR 1
+#endif
+#if RT_DEAL_SGPR
+    // the item being dealt: slot, first sample, unit count, tile origin -- five wave-uniform values in scalar registers (they
+    // lived in LDS while the camera's 23 words crowded the scalar file: five ds_read + v_readfirstlane per shading trip)
+    int d_slot = 0, d_s0 = 0, d_units = 0, d_i0 = 0, d_j0 = 0;
+#endif
 
     // every path of an item has ended: lane p stores pixel p's sums and clears the accumulator for its next item
     auto flush = [&](int slot, int i0, int j0, int chunk) {
@@ -1552,6 +1600,9 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                 // mask and the repeat decision)
                 bool at_box = is_box;
                 for (int rep = 0; rep < RT_BOX_REPEAT; rep++) {
+#ifdef RT_PROFILE_ACTIONS
+                    prof_box_steps += 1; prof_box_lane_steps += popc64(lane_mask(at_box));
+#endif
                     if (at_box) trav_box_step(mem, tv, tmin);
                     int h = tv.hdr;
                     at_box = h == make_hdr(K_BOX, 0);
@@ -1643,7 +1694,11 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
 #pragma unroll
                         for (int k = 0; k < NS; k++)
                             if (lane_mask(kind0 != K_IDLE && (pp >> TSH) == k)) free_slots &= ~(1u << k);
+#if RT_DEAL_SGPR
+                        const int first = d_slot + 1; // 1 .. NS
+#else
                         const int first = wsl(WS_CUR_SLOT) + 1; // 1 .. NS
+#endif
                         const unsigned rot = ((free_slots >> first) | (free_slots << (NS - first))) & ((1u << NS) - 1u);
                         if (rot) {
                             int t = first + __builtin_ctz(rot);
@@ -1670,15 +1725,24 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                             if (lane == 0) {
                                 ws[4 * t + WS_SLOT_I0] = ti * 8; ws[4 * t + WS_SLOT_J0] = tj * LdsLayout<R>::tile_h; ws[4 * t + WS_SLOT_CHUNK] = chunk;
                                 ws[4 * t + WS_SLOT_VALID] = got ? 1 : 0;
+#if !RT_DEAL_SGPR
                                 ws[WS_CUR_SLOT] = t; ws[WS_CUR_S0] = s0; ws[WS_N_UNITS] = n_new;
+#endif
                             }
+#if RT_DEAL_SGPR
+                            d_slot = t; d_s0 = s0; d_units = n_new; d_i0 = ti * 8; d_j0 = tj * LdsLayout<R>::tile_h;
+#endif
                             units_left = got ? n_new : -1;
                         }
                     }
                     if (units_left > 0) {
                         // deal units to the idle lanes: rank among the asking lanes + the item's cursor
+#if RT_DEAL_SGPR
+                        const int cur_slot = d_slot, cur_s0 = d_s0, n_item_units = d_units, cur_i0 = d_i0, cur_j0 = d_j0;
+#else
                         const int cur_slot = wsl(WS_CUR_SLOT), cur_s0 = wsl(WS_CUR_S0), n_item_units = wsl(WS_N_UNITS);
                         const int cur_i0 = wsl(4 * cur_slot + WS_SLOT_I0), cur_j0 = wsl(4 * cur_slot + WS_SLOT_J0);
+#endif
                         const int slot6 = cur_slot << TSH;
                         int next_unit = n_item_units - units_left;
                         bool need = kind0 == K_IDLE;
@@ -1833,6 +1897,8 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
         atomicAdd(&counters[34], prof_ready);
         atomicAdd(&counters[35], prof_all);
         atomicAdd(&counters[36], prof_tail);
+        atomicAdd(&counters[56], prof_box_steps);
+        atomicAdd(&counters[57], prof_box_lane_steps);
     }
 #endif
 }

@@ -22,6 +22,6 @@ def frame_shards(n_frames: int, world: int, rank: int) -> list[int]:
 def reduce_accum(accum, dst: int = 0):
     """Sum the ranks' accumulation buffers onto `dst` (torch.distributed: nccl == RCCL on ROCm)."""
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():  # (a one-rank group reduces onto itself: the same call path, nothing moves)
         dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
     return accum
