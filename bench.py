@@ -320,6 +320,7 @@ def run_rank(a, cfg, W, H, spp, depth, rank, world, dev, device, backend, groupe
                     ds_m.render_device(c, accum.data_ptr(), seed=1984, precision=abi.RT_PREC_F32, stream=stream)
                     ds_m.tonemap_device(accum.data_ptr(), 1.0 / (n * n), H * W, rgb.data_ptr(), stream=stream)
                 seq_ev[label][1].record()
+            torch.cuda.current_stream().synchronize()  # (so that the host's build times below are not waits for the frames above)
             seq_ev["bounce"][0].record()
             host_ms = 0.0
             for f in bounce_frames:

@@ -534,7 +534,17 @@ static void on_render(camera &cam, const hittable &world, const hittable &lights
     }
 
     if (g_mode == "render" || g_mode == "render_nocheck") {
-        const int W = cam.image_width, H = cam.image_height;
+        // REFGEN_WINDOW="x0,y0,w,h" (render_nocheck only): just that pixel window of the camera's frame -- the reference's own
+        // get_ray / ray_color on pixels (x0 + i, y0 + j) of the FULL-SIZE camera (a 64 x 64 window of the 1920 x 1080 frame
+        // at tens of thousands of samples is what a pixel-level check of a headline frame can afford)
+        int x0 = 0, y0 = 0, W = cam.image_width, H = cam.image_height;
+        if (const char *w = getenv("REFGEN_WINDOW")) {
+            if (g_mode != "render_nocheck" || sscanf(w, "%d,%d,%d,%d", &x0, &y0, &W, &H) != 4 || x0 < 0 || y0 < 0 || W < 1 || H < 1 ||
+                x0 + W > cam.image_width || y0 + H > cam.image_height) {
+                fprintf(stderr, "refgen: bad REFGEN_WINDOW\n");
+                exit(2);
+            }
+        }
         std::vector<double> sums((size_t)W * H * 3);
         std::vector<int32_t> bytes((size_t)W * H * 3);
         srand(g_seed);
@@ -543,7 +553,7 @@ static void on_render(camera &cam, const hittable &world, const hittable &lights
                 color pixel_color(0, 0, 0);
                 for (int s_j = 0; s_j < cam.sqrt_spp; s_j++)
                     for (int s_i = 0; s_i < cam.sqrt_spp; s_i++) {
-                        ray r = cam.get_ray(i, j, s_i, s_j);
+                        ray r = cam.get_ray(x0 + i, y0 + j, s_i, s_j);
                         pixel_color += cam.ray_color(r, cam.max_depth, world, lights);
                     }
                 size_t o = 3 * ((size_t)j * W + i);

@@ -8,10 +8,11 @@ origin, hit point, sphere centre + radius).  Moving a surface or the origin by d
 delta / |cos(theta)| along the ray (theta = angle between ray and normal), so
 
     |dt| / t  <=  C * eps * M / (dist * |cos theta|),         dist = t * |d|  (world units travelled)
-    |dn|      <=  C * eps * M * (1 + 1/|cos theta|) / r       sphere of radius r (n = (p - c) / r); constant normals: 4 eps
+    |dn|      <=  C_N * eps * M * (1 + 1/|cos theta|) / r     sphere of radius r (n = (p - c) / r); constant normals: 16 eps
     medium    :   t = t1 + hd / |d|,  hd = -(1/density) * ln(xi):  |d hd| <= (1/density) * (2 eps + 2 eps |ln xi|)
 
-with C = 8 covering the handful of roundings on the way.  north_star's 1e-5 holds wherever this bound is below it; where
+with C = 6.2 and C_N = 2.7 covering the handful of roundings on the way (set from the measured distribution, see below; cos theta is
+the ray's true grazing angle, no floor -- the most grazing fixture ray has |cos theta| = 0.004).  north_star's 1e-5 holds wherever this bound is below it; where
 the bound is larger (first_scene's r = 1000 ground seen at a grazing angle: eps * 1000 / (10 * 0.1) = 6e-5; final_scene's
 r = 5000 fog boundary) float CANNOT do better, and the tests then require measured <= bound instead.
 
@@ -28,7 +29,11 @@ import numpy as np
 from raytracing_amd import abi
 
 EPS32 = 2.0 ** -24
-C = 8.0
+# The constants of the bounds: what the worst fixture ray needs, plus 25 % (measured / bound over all 17 221 hit rays of the six
+# batches, tools/f32_parity_report.py, round 3: t worst 0.62 of the bound at C = 8 -> 4.96 -> 6.2; normals worst 0.266 -> 2.13 ->
+# 2.7).  The distribution is in tests/golden/f32_parity_table.json ("t_over_bound", "n_over_bound": p50 2 %, p99 < 40 % of the bound).
+C = 6.2    # distances, and the position uncertainty that classifies primitive-id mismatches
+C_N = 2.7  # sphere normals
 BAR = 1e-5  # north_star: t and normals within 1e-5 relative
 
 
@@ -207,7 +212,7 @@ def _extent(sc, nid):
 def _cos_theta(ray, hit):
     d = np.array(ray["dir"], dtype=np.float64)
     c = abs(float(np.array(hit["normal"]) @ d)) / math.sqrt(d @ d)
-    return max(c, 1e-3)
+    return max(c, 1e-9)  # the ray's true grazing angle (no floor that would widen the bound; 1e-9 only guards the division)
 
 
 def _same_surface(sc, a, b):
@@ -255,7 +260,7 @@ def classify(sc: abi.Scene, rays, ref, got, xi=None):
             if kind == abi.RT_NODE_MEDIUM:
                 x = float(xi[k]) if xi is not None else 0.5
                 bound_t += dens * (2 * EPS32 + 2 * EPS32 * abs(math.log(max(x, 1e-300)))) * C / dist
-            bound_n = 4 * EPS32 * 4 if radius is None else C * EPS32 * M * (1 + 1 / cos) / radius
+            bound_n = 4 * EPS32 * 4 if radius is None else C_N * EPS32 * M * (1 + 1 / cos) / radius
             rel_t = abs(float(got["t"][k]) - float(h["t"])) / abs(float(h["t"]))
             dn = float(np.abs(np.array(got["normal"][k]) - np.array(h["normal"])).max())
             rows.append(dict(index=k, status="same", prim=r, kind=kind, rel_t=rel_t, dn=dn, bound_t=bound_t, bound_n=bound_n,
@@ -304,6 +309,13 @@ def classify(sc: abi.Scene, rays, ref, got, xi=None):
     return rows
 
 
+def _quantiles(v):
+    if not v:
+        return {}
+    a = np.sort(np.asarray(v, dtype=np.float64))
+    return {q: float(f"{a[min(len(a) - 1, int(p * len(a)))]:.4g}") for q, p in (("p50", 0.5), ("p90", 0.9), ("p99", 0.99), ("p999", 0.999), ("max", 1.0))}
+
+
 def summarise(rows):
     same = [r for r in rows if r["status"] == "same"]
     solid = [r for r in same]
@@ -320,4 +332,8 @@ def summarise(rows):
         max_rel_t=max((r["rel_t"] for r in solid), default=0.0), max_dn=max((r["dn"] for r in solid), default=0.0),
         max_t_over_bound=max((r["rel_t"] / r["bound_t"] for r in solid), default=0.0),
         max_n_over_bound=max((r["dn"] / r["bound_n"] for r in solid), default=0.0),
+        # distribution of measured / bound over the rays with the reference's primitive (the bound's constant C is set from it)
+        t_over_bound_quantiles=_quantiles([r["rel_t"] / r["bound_t"] for r in solid]),
+        n_over_bound_quantiles=_quantiles([r["dn"] / r["bound_n"] for r in solid]),
+        min_cos=min((r["cos"] for r in solid), default=1.0), max_bound_t=max((r["bound_t"] for r in solid), default=0.0),
         exceptions=exc, mismatches=[{k: (float(f"{v:.6g}") if isinstance(v, float) else v) for k, v in r.items()} for r in mism])

@@ -195,3 +195,51 @@ def test_animation_frame_1080p(gpu_ctx, method, frame):
         assert 0.2 < float(lin.mean()) < 1.5  # a lit sky-blue scene, not black, not saturated
     finally:
         ds.close()
+
+
+# ---- pixel level at the headline resolution -----------------------------------------------------------------------
+@pytest.mark.parametrize("n,name", [(3, "final_scene"), (4, "mesh_scene")])
+def test_full_resolution_pixel_window_matches_reference(gpu_ctx, n, name):
+    """A 64 x 64 PIXEL WINDOW of the 1920 x 1080 frame, pixel for pixel, no box averaging: the compiled reference's own
+    get_ray / ray_color on pixels (x0 + i, y0 + j) of the full-size camera, 8 runs x 2 500 spp (tests/golden/win{n}.npz), against
+    the float kernels on the same pixels at 40 000 spp.  The window's camera is the full-size camera with pixel00_loc moved to
+    (x0, y0) -- rt_camera carries pixel00_loc and the pixel deltas explicitly -- so pixel footprints, the stratified jitter
+    inside a pixel and everything behind them are the 1080p frame's.  Bar: the reference's own noise.  With sigma^2 the
+    per-pixel variance of a 20 000-spp mean, two halves of the reference differ by 4 sigma^2 and GPU (40 000 spp) against the
+    whole reference by 1.5 sigma^2 if -- and only if -- both estimate the same image: 4.3 dB more PSNR for Gaussian noise, and
+    a median relative deviation sqrt(1.5 / 4) = 0.61 of the halves'.  Measured (round 3): mesh_scene 45.9 dB against 42.1 for the
+    halves, median deviation 0.0187 against 0.0295 (ratio 0.63); final_scene 25.7 against 23.5 dB (its estimator is heavy-tailed
+    -- the misplaced light sampling of cpuRenderer.cpp:374 makes fireflies that the 8-bit clamp turns into non-Gaussian errors --
+    so the PSNR gain is 2.2 dB), median deviation 0.141 against 0.219 (ratio 0.65).  A half-pixel offset or a wrong footprint
+    shows on every edge of the window and in the median."""
+    w = fx.window(n)
+    if w is None:
+        pytest.skip("window fixture not generated")
+    cam_full, (x0, y0), mean, spp_ref, runs = w
+    from raytracing_amd import scenes as scn
+    scene = scn.build(name, 1920, 1080, 1000, 50)
+    big = scene.camera
+    for f in ("center", "pixel00_loc", "pixel_delta_u", "pixel_delta_v"):  # the scene function's 1080p camera IS the fixture's
+        np.testing.assert_allclose(big[f][0], cam_full[f][0], rtol=1e-13, atol=1e-13)
+    side = mean.shape[0]
+    cam = big.copy()
+    cam["image_width"], cam["image_height"] = side, side
+    cam["pixel00_loc"][0] = big["pixel00_loc"][0] + x0 * big["pixel_delta_u"][0] + y0 * big["pixel_delta_v"][0]
+    cam = fx.with_size(cam, sqrt_spp=200, max_depth=50)
+    ds = gpu_ctx.upload(scene)
+    try:
+        acc, _, st = ds.render(cam, seed=77, precision=abi.RT_PREC_F32, want_rgb8=False)
+    finally:
+        ds.close()
+    assert st["samples"] == side * side * 40000
+    lin = np.nan_to_num(acc.astype(np.float64), nan=0.0, posinf=0.0, neginf=0.0) / 40000.0
+    r64 = runs.astype(np.float64)
+    psnr = fx.psnr8(O.write_color(lin, 1.0), O.write_color(mean, 1.0))
+    halves = fx.psnr8(O.write_color(r64[:4].mean(axis=0), 1.0), O.write_color(r64[4:].mean(axis=0), 1.0))
+    # the same in linear radiance, robust against the estimator's fireflies: median relative deviation per pixel channel
+    dev = np.abs(lin - mean) / np.maximum(mean, 1e-3)
+    dev_ref = np.abs(r64[:4].mean(axis=0) - r64[4:].mean(axis=0)) / np.maximum(mean, 1e-3)
+    print(f"{name} window ({x0}, {y0}) {side}x{side} at 1080p: PSNR vs reference ({spp_ref} spp) {psnr:.1f} dB; reference half against half "
+          f"{halves:.1f} dB; median relative deviation {np.median(dev):.4f} (reference halves: {np.median(dev_ref):.4f})")
+    assert psnr >= halves + 1.5, "pixel-level disagreement beyond the reference's own noise"
+    assert np.median(dev) <= 0.75 * np.median(dev_ref), "median deviation: expected 0.61 of the reference halves' for the same image"

@@ -32,7 +32,8 @@ for n in (1, 2, 3, 4, 6, "box3"):
     print(f"scene {n}: {rep['n_rays']} rays, {rep['n_same']} same id, {rep['n_tie']} equal-t ties ({rep['n_same_surface']} of them coplanar faces of one material), {rep['n_grazing']} grazing, "
           f"{rep['n_unexplained_id']} unexplained ids; over 1e-5: t {rep['n_t_over']} (max {rep['max_rel_t']:.3g}, max/bound {rep['max_t_over_bound']:.3g}), "
           f"normal {rep['n_n_over']} (max {rep['max_dn']:.3g}, max/bound {rep['max_n_over_bound']:.3g})")
-    for r in rep["exceptions"][:14]:
+    print(f"    measured / bound (C = {fb.C}): t {rep['t_over_bound_quantiles']}  normal {rep['n_over_bound_quantiles']}  min cos {rep['min_cos']:.3g}  largest t-bound {rep['max_bound_t']:.3g}")
+    for r in rep["exceptions"][:4]:
         print("   ", r)
     ds.close()
 json.dump(report, open("gpurun_out/f32_parity.json", "w"), indent=1)
@@ -40,6 +41,8 @@ json.dump(report, open("gpurun_out/f32_parity.json", "w"), indent=1)
 table = {}
 for name, rep in report.items():
     table[name] = {
+        "C": fb.C, "C_N": fb.C_N, "t_over_bound": rep["t_over_bound_quantiles"], "n_over_bound": rep["n_over_bound_quantiles"], "min_cos": rep["min_cos"],
+        "max_bound_t": rep["max_bound_t"],
         "n_rays": rep["n_rays"], "n_same_id": rep["n_same"], "n_tie_same_surface": rep["n_same_surface"], "max_rel_t": rep["max_rel_t"], "max_dn": rep["max_dn"],
         "beyond_1e-5": [{k: e[k] for k in ("index", "prim", "kind", "rel_t", "dn", "bound_t", "bound_n", "cos", "M", "dist")}
                         for e in rep["exceptions"]],
