@@ -127,21 +127,13 @@ def profiled_hbm_traffic():
 
 
 def partial_frame_bytes(W, H, n_strata):
-    """Algorithmic HBM bytes of one render_kernel launch: the sample range is cut into chunks (rt_abi.cpp plan_render: each
-    takes a third of what is left, minimum 32 -- a half / 16 below 360 strata) and every chunk writes a partial frame of
-    64-bit cells (the reduce kernel then reads them once and writes the float frame: as many bytes again + 12 B/pixel)."""
+    """Algorithmic HBM bytes of one render_kernel launch: a range of more than a few samples is cut into chunks whose work
+    items all add into ONE frame of 64-bit cells (atomic adds at item flush; rt_abi.cpp enqueue_render) -- 24 B / pixel,
+    written back once; a one-chunk launch writes the float frame itself (12 B / pixel).  (The conversion pass then reads
+    the cells and writes the floats: 36 B / pixel more, another kernel.)"""
     if n_strata <= 0:
         return 0
-    min_chunk, divisor = (32, 3) if n_strata >= 360 else (16, 2)
-    chunks, left = 0, n_strata
-    while left > 0:
-        take = max(left // divisor, min_chunk)
-        if take > left or left - take < min_chunk // 2:
-            take = left
-        left -= take
-        chunks += 1
-    cells = W * H * 3
-    return cells * 4 if chunks == 1 else chunks * cells * 8
+    return W * H * 3 * (8 if n_strata >= 24 else 4)
 
 
 def e2e_dropin(cfg, W, H, spp, depth, n_gpus, devices=None):

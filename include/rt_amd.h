@@ -276,11 +276,12 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
  * HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same inputs, same output (d_accum), same
  * kernels, asynchronous on `stream`; it calls no hipMalloc / hipFree.  What rt_render_device keeps in buffers it
  * allocates -- the kernels' counters and the per-chunk partial frames -- lives in a file-scope __device__ array of
- * 64 MiB that each GPU the library runs on holds until the process ends (4 KiB of counters + partial frames).
- * Limit: the partial frames (image_width * image_height * 3 cells each, 8-byte cells at RT_PREC_F32, 4-byte at RT_PREC_F64)
- * must fit 64 MiB - 4 KiB, so the sample range is cut into at most floor(that / one frame) chunks; a frame of which not
- * even two fit -- 1920x1080 at RT_PREC_F32 is 49.8 MB -- renders as ONE chunk straight into d_accum, whatever its size
- * (cost: the kernel ends on long work items instead of the decreasing schedule's short ones, a few percent at 1080p).
+ * 64 MiB that each GPU the library runs on holds until the process ends (4 KiB of counters + the frame scratch).
+ * Limit: the scratch of a render cut into several sample chunks must fit 64 MiB - 4 KiB.  At RT_PREC_F32 that is ONE frame
+ * of 64-bit cells the chunks add to atomically (image_width * image_height * 24 bytes: 1920x1080 is 49.8 MB and fits, up to
+ * 2 796 032 pixels); at RT_PREC_F64 a float frame per chunk (the number of chunks is capped to what fits).  A frame too large
+ * for that renders as ONE chunk straight into d_accum, whatever its size (cost: the kernel ends on long work items instead
+ * of the decreasing schedule's short ones, a few percent of a frame).
  * RT_PREC_F64 only after an allocating call has built the scene's f64 stream (else RT_ERR_INVALID with a message).
  * The array is shared by every call on that GPU and keeps the last call's contents (the entry point clears what must
  * start at zero): two calls that overlap on one GPU -- other streams, other contexts on the device -- race (rt_init of

@@ -389,12 +389,17 @@ int plan_render(rt_ctx *ctx, const rt_camera *cam, const rt_render_params *param
 // Enqueue one planned render on `stream` of the context's device (current on entry): counters cleared, the path-tracing
 // kernel into `partial` (n_chunks > 1) or straight into d_accum, then the fixed-order sum of the partial frames.  Nothing
 // here allocates or synchronises.
-size_t partial_cell_bytes(int precision) { return precision == RT_PREC_F32 ? 8 : 4; }
 
 int enqueue_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, int precision, const RenderPlan &pl_, void *partial,
                    unsigned long long *counters, float *d_accum, hipStream_t stream) {
     RenderPlan pl = pl_;
-    pl.rl.out_i64 = (precision == RT_PREC_F32 && pl.n_chunks > 1) ? 1 : 0;
+    // Several sample chunks.  float kernels: ONE frame of 64-bit fixed-point cells, zeroed here, that every chunk's work items
+    // add to with 64-bit atomics at flush (integer adds commute: the frame does not depend on who flushes when); then one
+    // pass turns it into floats.  HBM sees that frame once (24 B / pixel) instead of a partial frame per chunk written and
+    // read back (round 2: nine of them, 23 x the final frame).  double kernels (parity path): a float partial frame per
+    // chunk, summed in double in a fixed order.
+    const bool shared_frame = precision == RT_PREC_F32 && pl.n_chunks > 1;
+    pl.rl.out_i64 = shared_frame ? 2 : 0;
     if (pl.n_samples == 0) {
         HIP_TRY(ctx, hipMemsetAsync(d_accum, 0, pl.n_px * 3 * sizeof(float), stream));
         HIP_TRY(ctx, hipMemsetAsync(counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream));
@@ -403,12 +408,19 @@ int enqueue_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, int
     void *target = pl.n_chunks > 1 ? partial : (void *)d_accum;
     HIP_TRY(ctx, hipMemsetAsync(counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipMemsetAsync(counters + 37, 0xff, sizeof(unsigned long long), stream)); // [37]: a minimum (diagnostic builds)
+    if (shared_frame) HIP_TRY(ctx, hipMemsetAsync(partial, 0, pl.n_px * 3 * 8, stream));
     if (precision == RT_PREC_F64)
         HIP_TRY(ctx, launch_render<double>(scene->f64.sc, convert_camera<double>(*cam), pl.rl, target, counters, stream));
     else
         HIP_TRY(ctx, launch_render<float>(scene->f32.sc, convert_camera<float>(*cam), pl.rl, target, counters, stream));
-    if (pl.n_chunks > 1) HIP_TRY(ctx, launch_reduce_chunks(partial, pl.rl.out_i64 != 0, d_accum, pl.n_px * 3, pl.n_chunks, stream));
+    if (pl.n_chunks > 1) HIP_TRY(ctx, launch_reduce_chunks(partial, shared_frame, d_accum, pl.n_px * 3, shared_frame ? 1 : pl.n_chunks, stream));
     return RT_OK;
+}
+
+// bytes of scratch a planned render needs beyond d_accum: the shared 64-bit frame (float) or the per-chunk float frames (double)
+size_t partial_bytes_of(const RenderPlan &pl, int precision) {
+    if (pl.n_chunks <= 1) return 0;
+    return precision == RT_PREC_F32 ? pl.n_px * 3 * 8 : (size_t)pl.n_chunks * pl.n_px * 3 * 4;
 }
 
 void print_profile(rt_ctx *ctx, const unsigned long long *c) { // diagnostic builds (-DRT_PROFILE_*) fill counters[3..39]
@@ -679,7 +691,7 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (params->precision == RT_PREC_F64 && (rc = need_f64(ctx, scene)) != RT_OK) return rc;
     if (pl.n_chunks > 1) {
-        rc = ensure(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)pl.n_chunks * pl.n_px * 3 * partial_cell_bytes(params->precision));
+        rc = ensure(ctx, &ctx->partial, &ctx->partial_bytes, partial_bytes_of(pl, params->precision));
         if (rc) return rc;
     }
     if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
@@ -697,21 +709,22 @@ int rt_render_static(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
     if (!ctx || !scene || !cam || !params || !d_accum) return set_err(ctx, RT_ERR_INVALID, "rt_render_static: null argument");
     if (scene->ctx != ctx) return set_err(ctx, RT_ERR_INVALID, "rt_render_static: the scene belongs to another context");
     if (cam->image_width <= 0 || cam->image_height <= 0) return set_err(ctx, RT_ERR_INVALID, "render: bad camera");
-    // the partial frames live in the static array: that bounds the number of sample chunks.  A frame so large that not even
-    // two partial frames fit renders as ONE chunk, straight into d_accum (no scratch beyond the counters; the kernel then
-    // ends on long work items instead of the decreasing schedule's short ones: a few percent of a 1080p frame).
-    const int prec_ok = params->precision == RT_PREC_F64 ? RT_PREC_F64 : RT_PREC_F32;
-    const size_t frame_bytes = (size_t)cam->image_width * (size_t)cam->image_height * 3 * partial_cell_bytes(prec_ok);
+    // The scratch of a render with several sample chunks lives in the static array: float kernels need ONE frame of 64-bit
+    // cells (W * H * 24 bytes: 1920 x 1080 is 49.8 MB and fits), double kernels a float frame per chunk.  What does not fit
+    // renders as ONE chunk, straight into d_accum (no scratch beyond the counters; the kernel then ends on long work items
+    // instead of the decreasing schedule's short ones: a few percent of a frame).
+    const size_t cells = (size_t)cam->image_width * (size_t)cam->image_height * 3;
     const size_t room = RT_STATIC_SCRATCH_BYTES - RT_STATIC_COUNTER_BYTES;
+    const size_t max_chunks = params->precision == RT_PREC_F64 ? room / (cells * 4) : (cells * 8 <= room ? 65535 : 1);
     if (params->precision == RT_PREC_F64 && !scene->have_f64)
         return set_err(ctx, RT_ERR_INVALID, "rt_render_static: the f64 stream of this scene is built (and allocated) by the first "
                                             "RT_PREC_F64 call of rt_render_device / rt_trace_batch; make that call first");
     RenderPlan pl;
-    int rc = plan_render(ctx, cam, params, (int)std::min<size_t>(room / frame_bytes, 65535), pl); // (0 or 1: a single chunk)
+    int rc = plan_render(ctx, cam, params, (int)std::min<size_t>(max_chunks, 65535), pl); // (0 or 1: a single chunk)
     if (rc) return rc;
-    if (pl.n_chunks > 1 && (size_t)pl.n_chunks * frame_bytes > room) // (cannot happen: the plan honours its cap)
-        return set_err(ctx, RT_ERR_INVALID, "rt_render_static: " + std::to_string(pl.n_chunks) + " partial frames of " + std::to_string(frame_bytes) +
-                                                " bytes do not fit the static scratch (" + std::to_string(room) + " bytes): use rt_render_device");
+    if (partial_bytes_of(pl, params->precision) > room) // (cannot happen: the plan honours its cap)
+        return set_err(ctx, RT_ERR_INVALID, "rt_render_static: " + std::to_string(partial_bytes_of(pl, params->precision)) +
+                                                " bytes of scratch do not fit the static array (" + std::to_string(room) + " bytes): use rt_render_device");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // every use of the array's memory goes through the per-device pointer taken in rt_init
     unsigned long long *counters = reinterpret_cast<unsigned long long *>(ctx->static_scratch);
@@ -791,8 +804,7 @@ int rt_render_multi(rt_ctx *const *ctxs, const rt_scene *const *scenes, int n_de
         if (hipSetDevice(c->device) != hipSuccess) return fail_from(k, set_err(c, RT_ERR_HIP, "hipSetDevice failed"));
         if (params->precision == RT_PREC_F64 && (rc = need_f64(c, scenes[k])) != RT_OK) return fail_from(k, rc);
         if ((rc = ensure(c, (void **)&c->accum, &c->accum_bytes, bytes)) != RT_OK) return fail_from(k, rc);
-        if (plans[k].n_chunks > 1 &&
-            (rc = ensure(c, &c->partial, &c->partial_bytes, (size_t)plans[k].n_chunks * n_px * 3 * partial_cell_bytes(params->precision))) != RT_OK)
+        if (plans[k].n_chunks > 1 && (rc = ensure(c, &c->partial, &c->partial_bytes, partial_bytes_of(plans[k], params->precision))) != RT_OK)
             return fail_from(k, rc);
         if (hipEventRecord(c->ev0, nullptr) != hipSuccess) return fail_from(k, set_err(c, RT_ERR_HIP, "hipEventRecord failed"));
         if ((rc = enqueue_render(c, scenes[k], cam, params->precision, plans[k], c->partial, c->counter, c->accum, nullptr)) != RT_OK)

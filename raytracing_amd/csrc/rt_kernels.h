@@ -1312,6 +1312,7 @@ enum : int { RT_FX_SHIFT = 24 };
 #define RT_FX_CLAMP 1048576.0f
 struct I64Out { // what a float kernel stores per cell when several sample chunks are summed afterwards
     static constexpr long long nan_cell = 0x7fffffffffffffffll;
+    static constexpr unsigned long long nan_bit = 1ull << 63; // the shared frame (out_i64 == 2): a NaN sample sets the cell's top bit
 };
 template <class R> struct CellOf { using T = double; };
 template <> struct CellOf<float> { using T = unsigned long long; };
@@ -1372,7 +1373,8 @@ struct RenderArgs {
     int32_t chunk_size;      // > 0: equal chunks of this many samples; 0: the boundaries in chunk_start[]
     int32_t tiles_x, tiles_y;
     int32_t n_chunks;
-    int32_t out_i64;         // float kernels: `out` receives 64-bit fixed-point cells (chunks summed afterwards), else floats
+    int32_t out_i64;         // float kernels: 0 `out` receives floats; 1 64-bit fixed-point cells, one partial frame per chunk (summed
+                             // afterwards); 2 ONE zeroed frame of such cells that every chunk's items add to with 64-bit atomics
     int32_t shade_t;         // lanes that must wait before the shading block runs (RT_SHADE_T unless the launcher knows better)
     int32_t chunk_start[RT_MAX_SCHED_CHUNKS + 1];        // decreasing-size schedule (chunk c = [chunk_start[c], chunk_start[c+1]))
 };
@@ -1480,7 +1482,11 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                 for (int c = 0; c < 3; c++) {
                     const int bit = cell0 + c;
                     const bool nan = (ws[WS_NAN + slot * LdsLayout<R>::nan_words + (bit >> 5)] >> (bit & 31)) & 1;
-                    if (a.out_i64) out64[o + c] = nan ? I64Out::nan_cell : (long long)b[c];
+                    if (a.out_i64 == 2) { // ONE 64-bit frame for all sample chunks: integer adds commute, so the frame is the same
+                        unsigned long long *cell = reinterpret_cast<unsigned long long *>(out64) + (o - (size_t)chunk * cam.H * cam.W * 3 + c);
+                        if (nan) (void)__hip_atomic_fetch_or(cell, I64Out::nan_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else if (b[c] != 0ull) (void)__hip_atomic_fetch_add(cell, (unsigned long long)b[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else if (a.out_i64) out64[o + c] = nan ? I64Out::nan_cell : (long long)b[c];
                     else out[o + c] = nan ? __builtin_nanf("") : (float)((double)b[c] * (1.0 / 16777216.0));
                 }
             } else {

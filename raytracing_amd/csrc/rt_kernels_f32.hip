@@ -39,7 +39,7 @@ __global__ void reduce_chunks_i64_kernel(const long long *__restrict__ partial, 
     bool nan = false;
     for (int c = 0; c < n_chunks; c++) {
         const long long v = partial[(size_t)c * n + k];
-        nan = nan || v == I64Out::nan_cell;
+        nan = nan || v == I64Out::nan_cell || v < 0; // (v < 0: the NaN bit of the shared frame, I64Out::nan_bit)
         s += v;
     }
     out[k] = nan ? __builtin_nanf("") : (float)((double)s * (1.0 / 16777216.0));

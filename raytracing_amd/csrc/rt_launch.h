@@ -12,7 +12,7 @@ enum : int { RT_MAX_SCHED_CHUNKS_HOST = 24 }; // == RT_MAX_SCHED_CHUNKS of rt_ke
 struct RenderLaunch {
     uint32_t k0, k1;
     int32_t s_begin, s_end, chunk_size, n_chunks;
-    int32_t out_i64; // float kernels only: store 64-bit fixed-point cells (the per-chunk partial frames), not floats
+    int32_t out_i64; // float kernels only: 1 = 64-bit fixed-point cells, a partial frame per chunk; 2 = one shared frame, atomic adds
     int32_t chunk_start[25]; // used when chunk_size == 0 (n_chunks <= 24)
     int32_t n_cus;
 };
