@@ -448,6 +448,9 @@ void print_profile(rt_ctx *ctx, const unsigned long long *c) { // diagnostic bui
         std::fprintf(stderr, "[rt_amd profile] waves busy on average %.1f%% of the kernel's span (first start to last end); wave run time min %.1f%% max %.1f%% of the span\n",
                      span > 0 ? 100.0 * (double)c[39] / n_waves / span : 0.0, span > 0 ? 100.0 * (double)(~c[35]) / span : 0.0,
                      span > 0 ? 100.0 * (double)c[36] / span : 0.0);
+        std::fprintf(stderr, "[rt_amd profile] after the item cursor ran dry a wave kept running for %.1f%% of the span on average (max %.1f%%): %.0f trips per wave with %.1f lanes active\n",
+                     span > 0 ? 100.0 * (double)c[58] / n_waves / span : 0.0, span > 0 ? 100.0 * (double)c[59] / span : 0.0, (double)c[60] / n_waves,
+                     (double)c[61] / (double)(c[60] ? c[60] : 1));
     }
 }
 

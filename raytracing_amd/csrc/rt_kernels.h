@@ -1427,6 +1427,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     unsigned rays = 0;
 #ifdef RT_PROFILE_TAIL
     const unsigned long long t_tail0 = __builtin_amdgcn_s_memrealtime(); // device-wide constant-rate clock
+    unsigned long long t_dry = 0, dry_trips = 0, dry_lane_trips = 0; // when this wave found the item cursor exhausted; its trips from then on
 #endif
 #ifdef RT_PROFILE_ACTIONS
     unsigned long long prof_cyc[A_COUNT] = {}, prof_trips[A_COUNT] = {}, prof_lanes[A_COUNT] = {};
@@ -1513,6 +1514,9 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             const unsigned long long mb = lane_mask(is_box), ms = lane_mask(is_sph), ma = lane_mask(is_aab), mm = lane_mask(is_med),
                                      mo = lane_mask(is_oth), mr = lane_mask(ready);
             if (!(mb | ms | ma | mm | mo | mr) && units_left < 0) break; // nothing in flight, no items left: the wave is done
+#ifdef RT_PROFILE_TAIL
+            if (units_left < 0) { dry_trips += 1; dry_lane_trips += popc64(mb | ms | ma | mm | mo | mr); }
+#endif
             {
             // Run ONE block per trip: shading once enough lanes wait for it, else the record kind with the largest weighted
             // number of waiting lanes (score = count * weight, block id in the low bits -> one max chain).
@@ -1612,6 +1616,8 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     if (at_box) trav_box_step(mem, tv, tmin);
                     int h = tv.hdr;
                     at_box = h == make_hdr(K_BOX, 0);
+                    // (tried: going on while NO lane waits for anything else -- a wave's last long paths draining at the end of the
+                    // kernel take 2 300 mostly one-step trips on a 1/8 range -- 2 300 -> 2 030 trips, the drain no shorter, frame +0.5 %)
                     if (popc64(lane_mask(at_box)) < RT_BOX_REPEAT_MIN) break;
                 }
             }
@@ -1645,6 +1651,18 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     Cell *const px = acc + pp * 3;
                     if constexpr (sizeof(R) == 4) {
                         const float lv[3] = {L.x, L.y, L.z};
+                        if ((pp >> TSH) >= NS) {
+                            // an ORPHAN: the accumulator slot of this path's item was taken over while the path was still under way
+                            // (see the dealing step); its sample goes straight to the shared 64-bit frame -- integer adds commute
+                            unsigned long long *cell = reinterpret_cast<unsigned long long *>(out64) + (size_t)pixel * 3;
+#pragma unroll
+                            for (int c = 0; c < 3; c++) {
+                                if (lv[c] != lv[c]) (void)__hip_atomic_fetch_or(cell + c, I64Out::nan_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                else (void)__hip_atomic_fetch_add(cell + c, to_fixed(__builtin_amdgcn_fmed3f(lv[c], 0.0f, RT_FX_CLAMP)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            tv.hdr = K_IDLE;
+                            return;
+                        }
                         // the usual sample: three finite values in [0, 256) -> v * 2^24 fits 32 bits, one fma + one
                         // conversion per channel.  (Which branch a sample takes depends on the sample alone.)
                         const float sum = (L.x + L.y) + L.z; // NaN if any channel is
@@ -1706,9 +1724,15 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                         const int first = wsl(WS_CUR_SLOT) + 1; // 1 .. NS
 #endif
                         const unsigned rot = ((free_slots >> first) | (free_slots << (NS - first))) & ((1u << NS) - 1u);
-                        if (rot) {
-                            int t = first + __builtin_ctz(rot);
+                        // No slot without a path in flight (short items -- an 8-GPU rank's share of the samples -- and a few
+                        // 50-bounce paths use them up: 6 of 64 lanes sat idle per trip on a 1/8 range): when the chunks share one
+                        // 64-bit frame, the OLDEST slot is taken over anyway -- its sums so far are flushed now, and the paths of
+                        // its item that are still under way become orphans that add their sample to the frame themselves.
+                        const bool evict = !rot && a.out_i64 == 2;
+                        if (rot || evict) {
+                            int t = first + (rot ? __builtin_ctz(rot) : 0);
                             t = t >= NS ? t - NS : t;
+                            if (evict && kind0 != K_IDLE && (pp >> TSH) == t) pp = (pp & (TPX - 1)) | (NS << TSH);
                             const bool t_valid = wsl(4 * t + WS_SLOT_VALID) != 0;
                             if (t_valid) flush(t, wsl(4 * t + WS_SLOT_I0), wsl(4 * t + WS_SLOT_J0), wsl(4 * t + WS_SLOT_CHUNK));
                             int item = 0;
@@ -1739,6 +1763,9 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                             d_slot = t; d_s0 = s0; d_units = n_new; d_i0 = ti * 8; d_j0 = tj * LdsLayout<R>::tile_h;
 #endif
                             units_left = got ? n_new : -1;
+#ifdef RT_PROFILE_TAIL
+                            if (!got && t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime();
+#endif
                         }
                     }
                     if (units_left > 0) {
@@ -1880,6 +1907,10 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
         atomicAdd(&counters[39], t1 - t_tail0);
         atomicMax(&counters[36], t1 - t_tail0);
         atomicMax(&counters[35], ~(t1 - t_tail0)); // maximum of the complement = minimum duration (the counter starts at zero)
+        atomicAdd(&counters[58], t1 - (t_dry ? t_dry : t1)); // time this wave ran after it found the cursor exhausted
+        atomicMax(&counters[59], t1 - (t_dry ? t_dry : t1));
+        atomicAdd(&counters[60], dry_trips);
+        atomicAdd(&counters[61], dry_lane_trips);
     }
 #endif
 #ifdef RT_PROFILE_SHADE
