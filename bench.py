@@ -253,6 +253,11 @@ def run_rank(a, cfg, W, H, spp, depth, rank, world, dev, device, backend, groupe
     t_u0 = time.perf_counter()
     ds = ctx.upload(scene)
     flatten_upload_ms = (time.perf_counter() - t_u0) * 1e3
+    # upload-time probe (rt_scene_tune): the hierarchy build's candidate settings timed on this camera, the fastest stream kept
+    # -- outside the timed region, like the upload; reported below
+    t_t0 = time.perf_counter()
+    tune = None if anim else ds.tune(cam)
+    tune_ms = (time.perf_counter() - t_t0) * 1e3
     accum = torch.empty(H * W * 3, dtype=torch.float32, device=dev)
     rgb = torch.empty(H * W * 3, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
@@ -457,6 +462,8 @@ def run_rank(a, cfg, W, H, spp, depth, rank, world, dev, device, backend, groupe
                      "flops_per_sample": round(cfg["flops"], 1),
                      "note": "non-MFMA FP32 vector roof (SURVEY 8d): the scene is cache-resident, HBM is not the bound"},
         "host": {"scene_build_ms": round(host_build_ms, 2), "flatten_upload_ms": round(flatten_upload_ms, 2),
+                 "tune": None if tune is None else {"ms": round(tune_ms, 1), "chosen": tune["chosen"], "probe_ms": [round(x, 3) for x in tune["probe_ms"]],
+                                                    "note": "rt_scene_tune: 6 settings of the hierarchy build probed on this camera; 0 = the default"},
                  "device_build_upload_ms": None if device_build_ms is None else round(device_build_ms, 2),
                  "device_build_render_ms": None if device_build_render_ms is None else round(device_build_render_ms, 3),
                  "note": "scene function + host BVH build (C++ scene API); flattening + H2D upload of the f32 stream; the same "

@@ -238,6 +238,17 @@ void rt_scene_free(rt_scene *scene);
  * RT_PREC_F64: the parity stream is built lazily) }. */
 int rt_scene_info(const rt_scene *scene, int32_t *out);
 
+/* Upload-time probe (optional; no reference counterpart -- the reference builds one hierarchy, bvh.h:15-41, and lives with it).
+ * Which hierarchy the float path walks fastest depends on the rays the camera's paths actually send, and the landscape over
+ * the build's settings is rough (15-30 % between neighbouring bin counts).  This renders the first
+ * `probe_strata` strata (<= 0: chosen so that a probe traces ~60 M samples) of `cam`'s frame with the scene's current stream
+ * and with RT_TUNE_CANDIDATES - 1 other settings of the build (centroid bins 8 ... 16, child order), twice each, and leaves the
+ * scene with the fastest stream (a candidate must beat the incumbent by 2 %).  Closest hits do not depend on the hierarchy.
+ * ms_out (optional, RT_TUNE_CANDIDATES floats): the probe times, [0] = the stream the scene came with; chosen (optional): index
+ * of the winner.  Cost: ~(flatten + upload + 2 probes) per candidate -- 0.2-0.3 s at 1080p: for scenes rendered more than once. */
+#define RT_TUNE_CANDIDATES 6
+int rt_scene_tune(rt_ctx *ctx, rt_scene *scene, const rt_camera *cam, int probe_strata, float *ms_out, int32_t *chosen);
+
 /* Host-only (no GPU, no context): run the flattener on `desc` and report what rt_scene_upload would put on the device:
  * out[0] = record-stream units of the f32 (production) stream, out[1] = units of the f64 (parity) stream,
  * out[2] = box() lists fused into one AABOX record in the f32 stream (quad.h:103), out[3] = lights,

@@ -11,6 +11,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 RT_AMD_ABI_VERSION = 2
+RT_TUNE_CANDIDATES = 6  # include/rt_amd.h
 RT_ALL_STRATA = -1
 
 RT_OK, RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_NOMEM = 0, -1, -2, -3, -4

@@ -135,17 +135,19 @@ double wall_ms() {
 }
 
 // device_build (float stream only): the hierarchy is built on the device from the leaf records (rt_build.h)
-template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, DeviceScene<R> &ds, bool device_build = false) {
+template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, DeviceScene<R> &ds, bool device_build = false, const BuildKnobs *knobs = nullptr) {
     const bool timing = dev_knob("RT_AMD_TIMING") != nullptr; // development aid: where an upload's time goes
     const double t0 = wall_ms();
     Flat<R> f;
     std::string err;
     // RT_AMD_REF_ORDER (development knob): the float stream keeps the reference's bvh_nodes and visiting order
-    Flattener<R> fl(*desc, f, err, /*fuse_boxes=*/sizeof(R) == 4, /*own_hierarchy=*/sizeof(R) == 4 && !dev_knob("RT_AMD_REF_ORDER"));
+    Flattener<R> fl(*desc, f, err, /*fuse_boxes=*/sizeof(R) == 4, /*own_hierarchy=*/sizeof(R) == 4 && !dev_knob("RT_AMD_REF_ORDER"), knobs);
     std::vector<typename Flattener<R>::LeafRecord> leaves;
     std::vector<UnitT<R>> leaf_units, leaf_cold;
     double box_pad = 0;
-    int rc = device_build ? fl.run_leaves(leaves, box_pad) : fl.run();
+    int sub_begin = 0; // device build: where the boundary sub-streams of general media start in the leaf stream
+    size_t built_units = 0; // device build: units the device wrote (tree, sentinel, sub-streams)
+    int rc = device_build ? fl.run_leaves(leaves, box_pad, sub_begin) : fl.run();
     if (rc) return set_err(ctx, rc, err);
     std::vector<size_t> top, rest; // device build: leaves ahead of the tree / leaves of the tree
     size_t top_units = 0, rest_units = 0;
@@ -173,7 +175,9 @@ template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, Device
                     hi[a] = std::fmax(hi[a], leaves[k].hi[a]);
                 }
                 const double ar = area(leaves[k].lo, leaves[k].hi);
-                if (ar > best) { best = ar; arg = k; }
+                // (only single records go in front: a leaf of several records -- an instance, a general medium -- holds positions
+                // that the device relocates when it places the leaf)
+                if (ar > best && leaves[k].n <= 5 && (dec_int(f.stream[(size_t)leaves[k].off + 1].w[3]) & 15) != K_MEDIUM_GEN) { best = ar; arg = k; }
             }
             if (left < 2 || !(best >= top_share * area(lo, hi))) break;
             is_top[arg] = 1;
@@ -184,7 +188,9 @@ template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, Device
         }
         leaf_units.swap(f.stream);
         leaf_cold.swap(f.cold);
-        const size_t total = top_units + (rest.empty() ? 2 : built_stream_units(rest_units, rest.size()));
+        const size_t sub_units = leaf_units.size() - (size_t)sub_begin;
+        if (rest.empty() && sub_units) return set_err(ctx, RT_ERR_UNSUPPORTED, "device build: a general medium and no leaf for the tree");
+        const size_t total = top_units + (rest.empty() ? 2 : built_stream_units(rest_units, rest.size())) + sub_units; // an upper bound
         if (total > (size_t(1) << 25)) return set_err(ctx, RT_ERR_NOMEM, "flattened scene too large");
         f.stream.assign(total, UnitT<R>{}); // the device writes the tree's part of these two ranges
         f.cold.assign(total, UnitT<R>{});
@@ -240,13 +246,16 @@ template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, Device
             void *d_in = nullptr;
             HIP_TRY(ctx, hipMalloc(&d_in, in.host.size()));
             hipError_t e = hipMemcpy(d_in, in.host.data(), in.host.size(), hipMemcpyHostToDevice);
+            int built = 0;
             if (e == hipSuccess)
                 e = build_stream_on_device((const BuildLeaf *)((uint8_t *)d_in + o_bl), (int)bl.size(), (const UnitT<float> *)((uint8_t *)d_in + o_lu),
-                                           (const UnitT<float> *)((uint8_t *)d_in + o_lc), (int)rest_units,
+                                           (const UnitT<float> *)((uint8_t *)d_in + o_lc), (int)rest_units, sub_begin, (int)(leaf_units.size() - (size_t)sub_begin),
                                            (UnitT<float> *)(base + o_stream) + top_units, (UnitT<float> *)(base + o_cold) + top_units, c_lo, c_hi,
-                                           (float)box_pad, (int)top_units);
+                                           (float)box_pad, (int)top_units, &built);
             (void)hipFree(d_in);
             HIP_TRY(ctx, e);
+            built_units = top_units + (size_t)built;
+            if (built_units > f.stream.size()) return set_err(ctx, RT_ERR_HIP, "device build: the stream came out longer than its bound");
             if (timing) std::fprintf(stderr, "[rt_amd timing] device build of %zu leaves (%zu ahead of the tree): %.2f ms\n", bl.size(), top.size(), wall_ms() - t3);
         }
     }
@@ -260,7 +269,7 @@ template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, Device
     s.image_bytes = base + o_bytes;
     s.perlins = (const PerlinT<R> *)(base + o_perlin);
     s.lights = (const LightT<R> *)(base + o_lights);
-    s.n_units = (int)f.stream.size();
+    s.n_units = (int)(built_units ? built_units : f.stream.size());
     int cap = LaunchCfg<R>::lds_bytes / (int)sizeof(UnitT<R>);
     if (ctx->lds_limit_units >= 0 && ctx->lds_limit_units < cap) cap = ctx->lds_limit_units;
     // the stream is staged into LDS whole or not at all (rt_kernels.h, Mem); the shading tables whenever they fit behind it
@@ -600,6 +609,70 @@ int rt_scene_info(const rt_scene *scene, int32_t *out /* [4]: flat nodes, lights
     out[1] = scene->f32.sc.n_lights;
     out[2] = (int32_t)scene->f32.bytes;
     out[3] = (int32_t)scene->f64.bytes;
+    return RT_OK;
+}
+
+// The candidate settings of rt_scene_tune: the default first (a candidate must beat it by 2 % to replace it), then the
+// neighbours that won on one or another of the reference's scenes in round 2's sweeps (bins 8 ... 16, larger box / larger box
+// area per leaf first).
+static const struct { int bins, order; } kTuneCandidates[RT_TUNE_CANDIDATES] = {{12, 1}, {8, 1}, {16, 1}, {10, 1}, {12, 5}, {16, 5}};
+
+int rt_scene_tune(rt_ctx *ctx, rt_scene *scene, const rt_camera *cam, int probe_strata, float *ms_out, int32_t *chosen) {
+    if (!ctx || !scene || !cam) return set_err(ctx, RT_ERR_INVALID, "rt_scene_tune: null argument");
+    if (scene->ctx != ctx) return set_err(ctx, RT_ERR_INVALID, "rt_scene_tune: the scene belongs to another context");
+    if (cam->image_width <= 0 || cam->image_height <= 0 || cam->sqrt_spp <= 0) return set_err(ctx, RT_ERR_INVALID, "rt_scene_tune: bad camera");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int n_strata = cam->sqrt_spp * cam->sqrt_spp;
+    const size_t n_px = (size_t)cam->image_width * cam->image_height;
+    if (probe_strata <= 0) { // enough samples for the differences to show above a launch's fixed cost: ~60 M, at least 16 strata
+        probe_strata = (int)std::min<size_t>((size_t)n_strata, std::max<size_t>(16, (size_t)60000000 / n_px));
+    }
+    if (probe_strata > n_strata) probe_strata = n_strata;
+    int rc = ensure(ctx, (void **)&ctx->accum, &ctx->accum_bytes, n_px * 3 * sizeof(float));
+    if (rc) return rc;
+    rt_render_params p{};
+    p.seed = 0x74756e65ull; // any: the probe's image is thrown away
+    p.s_begin = 0;
+    p.s_end = probe_strata;
+    p.precision = RT_PREC_F32;
+    auto probe = [&](float &ms) {
+        ms = 0;
+        for (int rep = 0; rep < 2; rep++) {
+            rt_stats st{};
+            int r = rt_render_device(ctx, scene, cam, &p, ctx->accum, nullptr, &st);
+            if (r) return r;
+            ms = rep == 0 ? (float)st.kernel_ms : std::min(ms, (float)st.kernel_ms);
+        }
+        return (int)RT_OK;
+    };
+    int best_k = 0;
+    float best_ms = 0;
+    if ((rc = probe(best_ms)) != RT_OK) return rc; // candidate 0 is the stream the scene was uploaded with
+    if (ms_out) ms_out[0] = best_ms;
+    for (int k = 1; k < RT_TUNE_CANDIDATES; k++) {
+        BuildKnobs kn;
+        kn.bins = kTuneCandidates[k].bins;
+        kn.order = kTuneCandidates[k].order;
+        DeviceScene<float> cand;
+        rc = upload_one<float>(ctx, &scene->desc.d, cand, false, &kn);
+        if (rc != RT_OK) {
+            if (cand.blob) (void)hipFree(cand.blob);
+            return rc;
+        }
+        std::swap(scene->f32, cand); // the scene renders from the candidate now; `cand` holds what it had
+        float ms = 0;
+        rc = probe(ms);
+        if (ms_out) ms_out[k] = ms;
+        if (rc == RT_OK && ms < 0.98f * best_ms) { // keep the candidate
+            best_ms = ms;
+            best_k = k;
+        } else {
+            std::swap(scene->f32, cand); // back to the incumbent
+        }
+        if (cand.blob) (void)hipFree(cand.blob);
+        if (rc != RT_OK) return rc;
+    }
+    if (chosen) *chosen = best_k;
     return RT_OK;
 }
 

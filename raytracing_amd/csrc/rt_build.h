@@ -20,16 +20,19 @@ struct BuildLeaf {   // one leaf record of the leaf stream
     int32_t off, n;     // its units in the leaf stream
 };
 
-// units of the finished stream: the leaves, a BOX record per internal node of the binary tree, the sentinel
+// upper bound of the units of the finished stream: the leaves, a BOX record per internal node of the binary tree, the sentinel
+// (nodes whose box is nearly as large as their parent's get no BOX record: the stream usually comes out shorter)
 inline size_t built_stream_units(size_t leaf_units, size_t n_leaves) { return leaf_units + (n_leaves > 1 ? 2 * (n_leaves - 1) : 0) + 2; }
 
-// d_leaves / d_leaf_units / d_leaf_cold: device copies of the leaf table and the leaf stream (+ its cold units).
-// d_stream / d_cold: built_stream_units() units each.  c_lo / c_hi: bounds of the leaves' centroids (for the Morton grid).
-// box_pad: see Flattener::run (flat float boxes).  link_base: units in front of d_stream[0] in the scene's stream (leaves the
-// host put ahead of the tree): skip links are positions in the whole stream.  Synchronous: returns after the stream is complete.
+// d_leaves / d_leaf_units / d_leaf_cold: device copies of the leaf table and the leaf stream (+ its cold units); units
+// [sub_from, sub_from + sub_units) of the leaf stream are the boundary sub-streams of general media (placed behind the
+// sentinel).  d_stream / d_cold: room for built_stream_units() units each.  c_lo / c_hi: bounds of the leaves' centroids (for
+// the Morton grid).  box_pad: see Flattener::run (flat float boxes).  link_base: units in front of d_stream[0] in the scene's
+// stream (leaves the host put ahead of the tree): links are positions in the whole stream.  *built_units: units written from
+// d_stream[0] on (tree, sentinel, sub-streams).  Synchronous: returns after the stream is complete.
 hipError_t build_stream_on_device(const BuildLeaf *d_leaves, int n_leaves, const UnitT<float> *d_leaf_units, const UnitT<float> *d_leaf_cold,
-                                  int leaf_units, UnitT<float> *d_stream, UnitT<float> *d_cold, const float c_lo[3], const float c_hi[3],
-                                  float box_pad, int link_base = 0);
+                                  int leaf_units, int sub_from, int sub_units, UnitT<float> *d_stream, UnitT<float> *d_cold, const float c_lo[3],
+                                  const float c_hi[3], float box_pad, int link_base, int *built_units);
 
 } // namespace rtamd
 #endif

@@ -50,14 +50,39 @@ template <class R> inline void cvt3(const double *s, R *d) {
     cvt(s[2], d[2]);
 }
 
+// Settings of the float stream's hierarchy build (Flattener::build).  The defaults are the best single setting over the
+// reference's five configurations; rt_scene_tune (rt_abi.cpp) times a few others on the caller's camera and keeps the fastest.
+struct BuildKnobs {
+    double thr2 = 0.8, thrn = 0.95; // a node of 2 / of more leaves gets a BOX record if its area is below this share of its parent's
+    int order = 1;                  // which child goes first: see build()
+    int bins = 12;
+    double axis_min = 0;            // only axes whose centroid extent is at least this share of the widest are split
+    double overlap = 0.1;           // weight of the area the two sides of a split share, in the split's cost (0 -> 0.1:
+                                    // final_scene 635 -> 623, cornell_box 105 -> 103, mesh_scene 477 -> 471; 1.0: 665)
+    uint32_t jitter = 0;            // != 0: seed of a randomised build (see build(): bin grid shifted per node, near-ties broken at random)
+    double jitter_eps = 0.03;       //   candidates within this share of the cheapest split count as ties
+    BuildKnobs() { // development knobs
+        if (const char *e = dev_knob("RT_AMD_BVH_JITTER")) jitter = (uint32_t)std::atoll(e);
+        if (const char *e = dev_knob("RT_AMD_BVH_EPS")) jitter_eps = std::atof(e);
+        if (const char *e = dev_knob("RT_AMD_BVH_T2")) thr2 = std::atof(e);
+        if (const char *e = dev_knob("RT_AMD_BVH_TN")) thrn = std::atof(e);
+        if (const char *e = dev_knob("RT_AMD_BVH_ORDER")) order = std::atoi(e);
+        if (const char *e = dev_knob("RT_AMD_BVH_AXIS_MIN")) axis_min = std::atof(e);
+        if (const char *e = dev_knob("RT_AMD_BVH_OVERLAP")) overlap = std::atof(e);
+        if (const char *e = dev_knob("RT_AMD_BVH_BINS")) bins = std::min(32, std::max(2, std::atoi(e)));
+    }
+};
+
 template <class R> class Flattener {
   public:
     // fuse_boxes: replace a hittable_list of six axis-aligned quads forming a closed box (quad.h:103 box()) by one
     // AABOX record.  Used for the f32 stream only; the f64 parity stream keeps the reference's six quads.
     // own_hierarchy (f32 stream only): the stream's BOX records are not the reference's bvh_nodes but a surface-area-
     // heuristic hierarchy built here over ALL primitives of a frame (see emit_group()).
-    Flattener(const rt_scene_desc &d, Flat<R> &out, std::string &err, bool fuse_boxes, bool own_hierarchy = false)
-        : d_(d), f_(out), err_(err), fuse_(fuse_boxes), rebuild_(own_hierarchy) {}
+    Flattener(const rt_scene_desc &d, Flat<R> &out, std::string &err, bool fuse_boxes, bool own_hierarchy = false, const BuildKnobs *knobs = nullptr)
+        : d_(d), f_(out), err_(err), fuse_(fuse_boxes), rebuild_(own_hierarchy) {
+        if (knobs) knobs_ = *knobs;
+    }
 
     int run() {
         int rc = validate();
@@ -102,14 +127,16 @@ template <class R> class Flattener {
     }
 
     // For the device build (rt_build.h): the leaf records alone -- what run() would put under its own hierarchy -- written one
-    // after the other into f.stream / f.cold (no BOX records, no sentinel), with each leaf's place and bounds.
-    // RT_ERR_UNSUPPORTED if a leaf is more than one record (an instance that cannot be baked, a constant_medium with a
-    // boundary other than a static sphere): such scenes take the host build.
+    // after the other into f.stream / f.cold (no BOX records above them, no sentinel), with each leaf's place and bounds.  A
+    // leaf may be several records: an instance that stays an instance (XF_ENTER, its own hierarchy in the object frame --
+    // built here, on the host --, XF_EXIT), a constant_medium with a general boundary (its MEDIUM_GEN record; the boundaries'
+    // sub-streams follow ALL leaves, from unit `sub_begin` on).  Links inside such a leaf and inside the sub-streams are
+    // positions in THIS leaf stream: the device relocates them when it moves the records (rt_build.hip, emit_kernel).
     struct LeafRecord {
         int off, n;
         double lo[3], hi[3];
     };
-    int run_leaves(std::vector<LeafRecord> &leaves, double &box_pad) {
+    int run_leaves(std::vector<LeafRecord> &leaves, double &box_pad, int &sub_begin) {
         int rc = validate();
         if (rc) return rc;
         convert_tables();
@@ -126,12 +153,6 @@ template <class R> class Flattener {
         rc = collect(d_.world_root, 0, Rigid{}, false, 0, 0, lv);
         if (rc) return rc;
         for (const Leaf &l : lv) {
-            const rt_node &n = d_.nodes[l.id];
-            const bool simple = l.baked || n.kind == RT_NODE_SPHERE || n.kind == RT_NODE_QUAD || n.kind == RT_NODE_TRIANGLE ||
-                                n.kind == RT_NODE_LIST /* a fused box */ || is_obox(l.id) ||
-                                (n.kind == RT_NODE_MEDIUM && d_.nodes[n.a].kind == RT_NODE_SPHERE && d_.spheres[d_.nodes[n.a].a].dcenter[0] == 0 &&
-                                 d_.spheres[d_.nodes[n.a].a].dcenter[1] == 0 && d_.spheres[d_.nodes[n.a].a].dcenter[2] == 0);
-            if (!simple) return fail(RT_ERR_UNSUPPORTED, "device build: node " + std::to_string(l.id) + " is not a single record (instance or general medium)");
             LeafRecord r;
             r.off = (int)f_.stream.size();
             rc = emit_leaf(l, 0, 0);
@@ -143,6 +164,16 @@ template <class R> class Flattener {
             }
             leaves.push_back(r);
         }
+        sub_begin = (int)f_.stream.size();
+        for (size_t k = 0; k < pending_.size(); k++) { // as in run(): a general medium's boundary, with a sentinel of its own
+            const Pending pd = pending_[k];
+            f_.stream[pd.record].w[0] = I(pos());
+            rc = emit(pd.boundary, pd.ctx, 0);
+            if (rc) return rc;
+            const int e2 = push_units(2, -1);
+            f_.stream[e2 + 1].w[3] = I(make_hdr(K_READY, 0));
+        }
+        f_.has_gen_medium = pending_.empty() ? 0 : 1;
         return emit_lights();
     }
 
@@ -828,26 +859,6 @@ template <class R> class Flattener {
     // over the reference's five configurations: 12 bins, larger box first -- final_scene 634 (696 at 16 bins / area per
     // leaf), cornell_box 105 (125), mesh_scene 475 (482), first_scene 126 (122), bounce frame 86 (86).  (development knobs:
     // RT_AMD_BVH_BINS / _ORDER / _T2 / _TN; tools/grid_bvh.sh)
-    struct BuildKnobs {
-        double thr2 = 0.8, thrn = 0.95; // a node of 2 / of more leaves gets a BOX record if its area is below this share of its parent's
-        int order = 1;                  // which child goes first: see build()
-        int bins = 12;
-        double axis_min = 0;            // only axes whose centroid extent is at least this share of the widest are split
-        double overlap = 0.1;           // weight of the area the two sides of a split share, in the split's cost (0 -> 0.1:
-                                        // final_scene 635 -> 623, cornell_box 105 -> 103, mesh_scene 477 -> 471; 1.0: 665)
-        uint32_t jitter = 0;            // != 0: seed of a randomised build (see build(): bin grid shifted per node, near-ties broken at random)
-        double jitter_eps = 0.03;       //   candidates within this share of the cheapest split count as ties
-        BuildKnobs() { // development knobs
-            if (const char *e = dev_knob("RT_AMD_BVH_JITTER")) jitter = (uint32_t)std::atoll(e);
-            if (const char *e = dev_knob("RT_AMD_BVH_EPS")) jitter_eps = std::atof(e);
-            if (const char *e = dev_knob("RT_AMD_BVH_T2")) thr2 = std::atof(e);
-            if (const char *e = dev_knob("RT_AMD_BVH_TN")) thrn = std::atof(e);
-            if (const char *e = dev_knob("RT_AMD_BVH_ORDER")) order = std::atoi(e);
-            if (const char *e = dev_knob("RT_AMD_BVH_AXIS_MIN")) axis_min = std::atof(e);
-            if (const char *e = dev_knob("RT_AMD_BVH_OVERLAP")) overlap = std::atof(e);
-            if (const char *e = dev_knob("RT_AMD_BVH_BINS")) bins = std::min(32, std::max(2, std::atoi(e)));
-        }
-    };
     BuildKnobs knobs_;
 
     // idx[0 .. n): leaves of one node.  parent_area: area of the closest ancestor that has a BOX record.

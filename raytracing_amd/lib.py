@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")  # RT_AMD_LIB: diagnostic builds
 
 EXPORTS = ["rt_abi_sizeof", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_upload", "rt_scene_free",
-           "rt_scene_upload_device_build", "rt_scene_download_stream", "rt_scene_info", "rt_scene_flatten_info", "rt_scene_flatten_stream", "rt_trace_batch", "rt_render_device", "rt_tonemap_device", "rt_render",
+           "rt_scene_upload_device_build", "rt_scene_tune", "rt_scene_download_stream", "rt_scene_info", "rt_scene_flatten_info", "rt_scene_flatten_stream", "rt_trace_batch", "rt_render_device", "rt_tonemap_device", "rt_render",
            "rt_render_multi", "rt_render_static"]
 
 _lib = None
@@ -62,6 +62,8 @@ def load() -> C.CDLL:
     L.rt_scene_free.argtypes = [vp]
     L.rt_scene_info.restype = C.c_int
     L.rt_scene_info.argtypes = [vp, vp]
+    L.rt_scene_tune.restype = C.c_int
+    L.rt_scene_tune.argtypes = [vp, vp, vp, C.c_int, vp, vp]
     L.rt_scene_flatten_info.restype = C.c_int
     L.rt_scene_flatten_info.argtypes = [C.POINTER(abi.SceneDesc), C.c_int, vp]
     L.rt_scene_flatten_stream.restype = C.c_int
@@ -169,6 +171,15 @@ class DeviceScene:
         self.ctx.check(self.ctx.L.rt_scene_download_stream(self.h, units.ctypes.data, ids.ctypes.data, n.value, C.byref(n)),
                        "rt_scene_download_stream")
         return units, ids
+
+    def tune(self, camera: np.ndarray, probe_strata: int = 0) -> dict:
+        """rt_scene_tune: time the hierarchy build's candidate settings on `camera` and keep the fastest stream."""
+        cam = np.ascontiguousarray(camera, dtype=abi.camera_dtype).reshape(1)
+        ms = np.zeros(abi.RT_TUNE_CANDIDATES, dtype=np.float32)
+        chosen = np.zeros(1, dtype=np.int32)
+        rc = self.ctx.L.rt_scene_tune(self.ctx.h, self.h, cam.ctypes.data, probe_strata, ms.ctypes.data, chosen.ctypes.data)
+        self.ctx.check(rc, "rt_scene_tune")
+        return {"probe_ms": [float(x) for x in ms], "chosen": int(chosen[0])}
 
     def info(self) -> dict:
         out = np.zeros(5, dtype=np.int32)

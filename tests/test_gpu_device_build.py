@@ -18,10 +18,14 @@ pytestmark = pytest.mark.gpu
 
 
 def _scene(n):
-    return random_scene.build(int(n.split()[1]), single_records=True) if isinstance(n, str) else fx.scene(n)
+    if isinstance(n, str):
+        return random_scene.build(int(n.split()[1]), single_records=not n.endswith("full"))
+    return fx.scene(n)
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 4, "random 1", "random 2"])
+# (6 = cornell_smoke: box-bounded media -- MEDIUM_GEN leaves whose boundary sub-streams stand behind the sentinel --; "random 3
+# full": instances that stay instances -- leaves of several records with skip links of their own, relocated by the device)
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 6, "random 1", "random 2", "random 3 full"])
 def test_device_built_stream_structure_and_hits(gpu_ctx, n):
     sc = _scene(n)
     t0 = time.perf_counter()
@@ -37,7 +41,10 @@ def test_device_built_stream_structure_and_hits(gpu_ctx, n):
         kinds = [k for _, k in stream_check.records(units)]
         n_top = next((i for i, k in enumerate(kinds) if k == 0), n_leaves - 1)
         assert n_top <= 8 and all(k not in (0, 15) for k in kinds[:n_top])
-        assert n_box == n_leaves - n_top - 1, "a binary tree over the other leaves: one BOX record per internal node"
+        if n != 6 and not (isinstance(n, str) and n.endswith("full")):  # (BOX records inside instance leaves / sub-streams count too there)
+            # a binary tree over the other leaves: at most one BOX record per internal node -- a node whose box is nearly as
+            # large as its parent's gets none (the host build's rule)
+            assert n_box <= max(n_leaves - n_top - 1, 0)
         print(f"scene {n}: {n_leaves} leaves, {len(units)} units, upload with device build {t_build * 1e3:.1f} ms")
         if isinstance(n, str):
             rays = random_scene.rays(int(n.split()[1]))
@@ -68,16 +75,6 @@ def test_device_built_stream_structure_and_hits(gpu_ctx, n):
     finally:
         ds.close()
         host.close()
-
-
-@pytest.mark.parametrize("n", [6, "random 3 full"])
-def test_device_build_refuses_multi_record_leaves(gpu_ctx, n):
-    """cornell_smoke's box-bounded media and an instance of a list of quads (an instance that stays an instance) are more
-    than one record per leaf: the device build says so (the caller uses rt_scene_upload).  (cornell_box's rotated box is
-    ONE record, an OBOX, and is taken: the structure test above.)"""
-    sc = random_scene.build(3) if isinstance(n, str) else fx.scene(n)
-    with pytest.raises(lib.RtError):
-        gpu_ctx.upload(sc, device_build=True)
 
 
 def test_device_build_single_primitive_and_double_path(gpu_ctx):
