@@ -56,6 +56,9 @@ def parse_args(argv=None):
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end run of the C++ drop-in (rtamd_render)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="profiling runs: only the warm-up and timed launches and the ray-count pass (no tuning probes, no 1/8-range "
+                         "and device-build launches, no end-to-end child, no CPU baseline), so that per-kernel counter sums are per launch")
     ap.add_argument("--force-collective", action="store_true",
                     help="one rank: still create the process group and run the N-rank path's collectives (rehearsal of the RCCL branch)")
     return ap.parse_args(argv)
@@ -127,13 +130,22 @@ def profiled_hbm_traffic():
 
 
 def partial_frame_bytes(W, H, n_strata):
-    """Algorithmic HBM bytes of one render_kernel launch: a range of more than a few samples is cut into chunks whose work
-    items all add into ONE frame of 64-bit cells (atomic adds at item flush; rt_abi.cpp enqueue_render) -- 24 B / pixel,
-    written back once; a one-chunk launch writes the float frame itself (12 B / pixel).  (The conversion pass then reads
-    the cells and writes the floats: 36 B / pixel more, another kernel.)"""
+    """Algorithmic HBM bytes of one render_kernel launch: the sample range is cut into chunks (rt_abi.cpp plan_render: each
+    takes three quarters of what is left, minimum 32 -- two thirds / 16 below 360 strata) and every chunk writes a partial
+    frame of 64-bit cells, 24 B / pixel; a one-chunk launch writes the float frame itself, 12 B / pixel.  (The summing pass
+    then reads the partial frames once and writes the floats: another kernel.)"""
     if n_strata <= 0:
         return 0
-    return W * H * 3 * (8 if n_strata >= 24 else 4)
+    min_chunk, pct = (32, 75) if n_strata >= 360 else (16, 67)
+    chunks, left = 0, n_strata
+    while left > 0:
+        take = max(left * pct // 100, min_chunk)
+        if take > left or left - take < min_chunk // 2:
+            take = left
+        left -= take
+        chunks += 1
+    cells = W * H * 3
+    return cells * 4 if chunks == 1 else chunks * cells * 8
 
 
 def e2e_dropin(cfg, W, H, spp, depth, n_gpus, devices=None):
@@ -256,7 +268,7 @@ def run_rank(a, cfg, W, H, spp, depth, rank, world, dev, device, backend, groupe
     # upload-time probe (rt_scene_tune): the hierarchy build's candidate settings timed on this camera, the fastest stream kept
     # -- outside the timed region, like the upload; reported below
     t_t0 = time.perf_counter()
-    tune = None if anim else ds.tune(cam)
+    tune = None if anim or a.no_extras else ds.tune(cam)
     tune_ms = (time.perf_counter() - t_t0) * 1e3
     accum = torch.empty(H * W * 3, dtype=torch.float32, device=dev)
     rgb = torch.empty(H * W * 3, dtype=torch.uint8, device=dev)
@@ -404,7 +416,7 @@ def run_rank(a, cfg, W, H, spp, depth, rank, world, dev, device, backend, groupe
     # stream: reported figures, the timed frames above use the host-built stream.  None: the device build refuses the scene
     device_build_ms = device_build_render_ms = None
     try:
-        for _ in range(2):  # (the first call also loads the build kernels' code object)
+        for _ in range(0 if a.no_extras else 2):  # (the first call also loads the build kernels' code object)
             t_d0 = time.perf_counter()
             ds_dev = ctx.upload(scene, device_build=True)
             dt_d = (time.perf_counter() - t_d0) * 1e3
@@ -415,7 +427,7 @@ def run_rank(a, cfg, W, H, spp, depth, rank, world, dev, device, backend, groupe
     except lib.RtError:
         pass
     headline = a.config == "final" and (W, H, spp) == (1920, 1080, 1000)
-    if world == 1 and not anim and n * n >= 64:
+    if world == 1 and not anim and n * n >= 64 and not a.no_extras:
         # what each of 8 GPUs would render: one eighth of the strata of every pixel (north_star asks for the 8-GPU frame;
         # this is its kernel on one GPU -- the gap to 1/8 of the whole frame's kernel is the end-of-kernel tail)
         e_ms = kernel_ms_of(ds, cam, s_begin=0, s_end=(n * n) // 8)
@@ -470,9 +482,9 @@ def run_rank(a, cfg, W, H, spp, depth, rank, world, dev, device, backend, groupe
                          "upload with the hierarchy built on the device; render_kernel time of this rank's launch on that stream"},
     }
     out.update(extra)
-    if not a.no_e2e and not anim:
+    if not a.no_e2e and not anim and not a.no_extras:
         out["e2e"] = e2e_dropin(cfg, W, H, spp, depth, world, devices=rehearsal_devices)
-    if world == 1 and not a.no_cpu_baseline and not anim:
+    if world == 1 and not a.no_cpu_baseline and not anim and not a.no_extras:
         out["cpu_baseline"] = cpu_baseline(cfg["scene_id"], min(16, os.cpu_count() or 1))
     return out
 

@@ -289,7 +289,7 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
  * allocates -- the kernels' counters and the per-chunk partial frames -- lives in a file-scope __device__ array of
  * 64 MiB that each GPU the library runs on holds until the process ends (4 KiB of counters + the frame scratch).
  * Limit: the scratch of a render cut into several sample chunks must fit 64 MiB - 4 KiB.  At RT_PREC_F32 that is ONE frame
- * of 64-bit cells the chunks add to atomically (image_width * image_height * 24 bytes: 1920x1080 is 49.8 MB and fits, up to
+ * of 64-bit cells the chunks add to atomically (rt_render_device writes a partial frame per chunk instead) (image_width * image_height * 24 bytes: 1920x1080 is 49.8 MB and fits, up to
  * 2 796 032 pixels); at RT_PREC_F64 a float frame per chunk (the number of chunks is capped to what fits).  A frame too large
  * for that renders as ONE chunk straight into d_accum, whatever its size (cost: the kernel ends on long work items instead
  * of the decreasing schedule's short ones, a few percent of a frame).

@@ -48,7 +48,7 @@ struct rt_ctx {
     int n_cus = 256;
     // development knobs (environment RT_AMD_LDS_UNITS / RT_AMD_CHUNKS); -1 / 0 = library default
     int lds_limit_units = -1;
-    int min_chunk = 0, chunk_divisor = 0, max_chunk = 0;
+    int min_chunk = 0, chunk_divisor = 0, max_chunk = 0, chunk_pct = 0, frame_mode = 0;
 };
 
 template <class R> struct DeviceScene {
@@ -376,13 +376,17 @@ int plan_render(rt_ctx *ctx, const rt_camera *cam, const rt_render_params *param
         n_chunks = (n_samples + rl.chunk_size - 1) / rl.chunk_size;
     } else {
         const int min_chunk = ctx->min_chunk > 0 ? ctx->min_chunk : (n_samples >= 360 ? 32 : 16);
-        const int divisor = ctx->chunk_divisor > 1 ? ctx->chunk_divisor : (n_samples >= 360 ? 3 : 2); // measured on final_scene 1080p
+        const int divisor = ctx->chunk_divisor > 1 ? ctx->chunk_divisor : (n_samples >= 360 ? 3 : 2); // (round 2's schedule: a third / a half of what is left)
+        // round 3: each chunk takes THREE QUARTERS of what is left (two thirds of a short range): 961 strata are 720 + 180 + 61
+        // instead of nine chunks -- a third of the partial frames to write and sum, and 0.7 % less time (517 -> 519 at 1/2, 519.0 at
+        // 3/4; a 1/8 range 70.3 -> 69.5 ms at 2/3); the kernel still ends on its shortest items
+        const int pct = ctx->chunk_pct > 0 ? ctx->chunk_pct : (ctx->chunk_divisor > 1 ? 0 : (n_samples >= 360 ? 75 : 67));
         rl.chunk_size = 0;
         n_chunks = 0;
         int at = s_begin;
         rl.chunk_start[0] = at;
         while (at < s_end) {
-            int left = s_end - at, take = left / divisor;
+            int left = s_end - at, take = pct > 0 ? (int)((int64_t)left * pct / 100) : left / divisor;
             if (ctx->max_chunk > 0 && take > ctx->max_chunk) take = ctx->max_chunk;
             if (take < min_chunk) take = min_chunk;
             if (take > left || left - take < min_chunk / 2 || n_chunks == sched_cap - 1) take = left;
@@ -400,15 +404,19 @@ int plan_render(rt_ctx *ctx, const rt_camera *cam, const rt_render_params *param
 // here allocates or synchronises.
 
 int enqueue_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, int precision, const RenderPlan &pl_, void *partial,
-                   unsigned long long *counters, float *d_accum, hipStream_t stream) {
+                   unsigned long long *counters, float *d_accum, hipStream_t stream, bool shared_frame_wanted) {
     RenderPlan pl = pl_;
-    // Several sample chunks.  float kernels: ONE frame of 64-bit fixed-point cells, zeroed here, that every chunk's work items
-    // add to with 64-bit atomics at flush (integer adds commute: the frame does not depend on who flushes when); then one
-    // pass turns it into floats.  HBM sees that frame once (24 B / pixel) instead of a partial frame per chunk written and
-    // read back (round 2: nine of them, 23 x the final frame).  double kernels (parity path): a float partial frame per
-    // chunk, summed in double in a fixed order.
-    const bool shared_frame = precision == RT_PREC_F32 && pl.n_chunks > 1;
-    pl.rl.out_i64 = shared_frame ? 2 : 0;
+    // Several sample chunks, float kernels: 64-bit fixed-point cells, summed exactly (the frame does not depend on the cut
+    // into chunks or on who flushes when).  Two layouts:
+    //   a partial frame per chunk, written with plain stores and summed by one pass afterwards (rt_render_device: the
+    //   decreasing schedule is 3-4 chunks at 1080p, i.e. 3-4 x 24 B / pixel written and read once);
+    //   ONE zeroed frame that every chunk's work items add to with 64-bit atomics (rt_render_static: it fits the static
+    //   scratch whatever the number of chunks).  Same time; the atomics reach memory as 32-byte requests -- measured 1.23 GB
+    //   of L2 write requests per 1080p launch against 0.51 GB for nine partial frames -- so it is not the default.
+    // double kernels (parity path): a float partial frame per chunk, summed in double in a fixed order.
+    const bool shared_frame = precision == RT_PREC_F32 && pl.n_chunks > 1 && shared_frame_wanted;
+    const bool cells_i64 = precision == RT_PREC_F32 && pl.n_chunks > 1;
+    pl.rl.out_i64 = shared_frame ? 2 : (cells_i64 ? 1 : 0);
     if (pl.n_samples == 0) {
         HIP_TRY(ctx, hipMemsetAsync(d_accum, 0, pl.n_px * 3 * sizeof(float), stream));
         HIP_TRY(ctx, hipMemsetAsync(counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream));
@@ -422,14 +430,15 @@ int enqueue_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, int
         HIP_TRY(ctx, launch_render<double>(scene->f64.sc, convert_camera<double>(*cam), pl.rl, target, counters, stream));
     else
         HIP_TRY(ctx, launch_render<float>(scene->f32.sc, convert_camera<float>(*cam), pl.rl, target, counters, stream));
-    if (pl.n_chunks > 1) HIP_TRY(ctx, launch_reduce_chunks(partial, shared_frame, d_accum, pl.n_px * 3, shared_frame ? 1 : pl.n_chunks, stream));
+    if (pl.n_chunks > 1) HIP_TRY(ctx, launch_reduce_chunks(partial, cells_i64, d_accum, pl.n_px * 3, shared_frame ? 1 : pl.n_chunks, stream));
     return RT_OK;
 }
 
-// bytes of scratch a planned render needs beyond d_accum: the shared 64-bit frame (float) or the per-chunk float frames (double)
-size_t partial_bytes_of(const RenderPlan &pl, int precision) {
+// bytes of scratch a planned render needs beyond d_accum
+size_t partial_bytes_of(const RenderPlan &pl, int precision, bool shared_frame) {
     if (pl.n_chunks <= 1) return 0;
-    return precision == RT_PREC_F32 ? pl.n_px * 3 * 8 : (size_t)pl.n_chunks * pl.n_px * 3 * 4;
+    if (precision == RT_PREC_F32) return (shared_frame ? 1 : (size_t)pl.n_chunks) * pl.n_px * 3 * 8;
+    return (size_t)pl.n_chunks * pl.n_px * 3 * 4;
 }
 
 void print_profile(rt_ctx *ctx, const unsigned long long *c) { // diagnostic builds (-DRT_PROFILE_*) fill counters[3..39]
@@ -553,7 +562,8 @@ int rt_init(int device, rt_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cus = prop.multiProcessorCount;
     if (const char *e1 = dev_knob("RT_AMD_LDS_UNITS")) ctx->lds_limit_units = std::atoi(e1);
-    if (const char *e5 = dev_knob("RT_AMD_CHUNKS")) std::sscanf(e5, "%d,%d,%d", &ctx->min_chunk, &ctx->chunk_divisor, &ctx->max_chunk);
+    if (const char *e5 = dev_knob("RT_AMD_CHUNKS")) std::sscanf(e5, "%d,%d,%d,%d", &ctx->min_chunk, &ctx->chunk_divisor, &ctx->max_chunk, &ctx->chunk_pct);
+    if (const char *e6 = dev_knob("RT_AMD_FRAME_MODE")) ctx->frame_mode = std::atoi(e6); // 1: a partial frame per chunk, 2: one shared frame (atomics)
     *out = ctx;
     return RT_OK;
 }
@@ -767,11 +777,11 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (params->precision == RT_PREC_F64 && (rc = need_f64(ctx, scene)) != RT_OK) return rc;
     if (pl.n_chunks > 1) {
-        rc = ensure(ctx, &ctx->partial, &ctx->partial_bytes, partial_bytes_of(pl, params->precision));
+        rc = ensure(ctx, &ctx->partial, &ctx->partial_bytes, partial_bytes_of(pl, params->precision, ctx->frame_mode == 2));
         if (rc) return rc;
     }
     if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    rc = enqueue_render(ctx, scene, cam, params->precision, pl, ctx->partial, ctx->counter, d_accum, stream);
+    rc = enqueue_render(ctx, scene, cam, params->precision, pl, ctx->partial, ctx->counter, d_accum, stream, ctx->frame_mode == 2);
     if (rc) return rc;
     if (stats) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
@@ -798,14 +808,14 @@ int rt_render_static(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
     RenderPlan pl;
     int rc = plan_render(ctx, cam, params, (int)std::min<size_t>(max_chunks, 65535), pl); // (0 or 1: a single chunk)
     if (rc) return rc;
-    if (partial_bytes_of(pl, params->precision) > room) // (cannot happen: the plan honours its cap)
-        return set_err(ctx, RT_ERR_INVALID, "rt_render_static: " + std::to_string(partial_bytes_of(pl, params->precision)) +
+    if (partial_bytes_of(pl, params->precision, true) > room) // (cannot happen: the plan honours its cap)
+        return set_err(ctx, RT_ERR_INVALID, "rt_render_static: " + std::to_string(partial_bytes_of(pl, params->precision, true)) +
                                                 " bytes of scratch do not fit the static array (" + std::to_string(room) + " bytes): use rt_render_device");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // every use of the array's memory goes through the per-device pointer taken in rt_init
     unsigned long long *counters = reinterpret_cast<unsigned long long *>(ctx->static_scratch);
     void *partial = ctx->static_scratch + RT_STATIC_COUNTER_BYTES;
-    return enqueue_render(ctx, scene, cam, params->precision, pl, partial, counters, d_accum, (hipStream_t)stream_);
+    return enqueue_render(ctx, scene, cam, params->precision, pl, partial, counters, d_accum, (hipStream_t)stream_, /*shared_frame_wanted=*/true);
 }
 
 int rt_tonemap_device(rt_ctx *ctx, const float *d_accum, double scale, size_t n_pixels, uint8_t *d_rgb8, void *stream) {
@@ -880,10 +890,10 @@ int rt_render_multi(rt_ctx *const *ctxs, const rt_scene *const *scenes, int n_de
         if (hipSetDevice(c->device) != hipSuccess) return fail_from(k, set_err(c, RT_ERR_HIP, "hipSetDevice failed"));
         if (params->precision == RT_PREC_F64 && (rc = need_f64(c, scenes[k])) != RT_OK) return fail_from(k, rc);
         if ((rc = ensure(c, (void **)&c->accum, &c->accum_bytes, bytes)) != RT_OK) return fail_from(k, rc);
-        if (plans[k].n_chunks > 1 && (rc = ensure(c, &c->partial, &c->partial_bytes, partial_bytes_of(plans[k], params->precision))) != RT_OK)
+        if (plans[k].n_chunks > 1 && (rc = ensure(c, &c->partial, &c->partial_bytes, partial_bytes_of(plans[k], params->precision, false))) != RT_OK)
             return fail_from(k, rc);
         if (hipEventRecord(c->ev0, nullptr) != hipSuccess) return fail_from(k, set_err(c, RT_ERR_HIP, "hipEventRecord failed"));
-        if ((rc = enqueue_render(c, scenes[k], cam, params->precision, plans[k], c->partial, c->counter, c->accum, nullptr)) != RT_OK)
+        if ((rc = enqueue_render(c, scenes[k], cam, params->precision, plans[k], c->partial, c->counter, c->accum, nullptr, false)) != RT_OK)
             return fail_from(k, rc);
         if (hipEventRecord(c->ev1, nullptr) != hipSuccess) return fail_from(k, set_err(c, RT_ERR_HIP, "hipEventRecord failed"));
     }

@@ -404,6 +404,10 @@ RT_DEV bool aabox_t(const UnitT<R> &u0, const UnitT<R> &u1, V3<R> o, V3<R> inv, 
 // wave's schedule, so frames did not repeat (values one float ulp apart, now and then a different ray count).
 RT_DEV float fdot3(V3<float> a, V3<float> b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
 
+// (Tried in round 3: the traversal walking rays of UNIT direction -- a = d.d = 1 takes a reciprocal and four multiplies out of
+// every sphere / medium test and the square root and division out of the medium's path length -- with camera.h:300's 0.001
+// and constant_medium.h:27's 0.0001 scaled by |d| per ray.  The per-ray interval minimum is one more register of loop-carried
+// state and the normalisation runs in every shading trip: final_scene 517 -> 523 ms, first_scene 113.6 -> 117.1.  Not kept.)
 template <class R> RT_DEV bool sphere_t(V3<R> cc, R radius, V3<R> ro, V3<R> rd, R tmin, R tmax, R &t_out) { // sphere.h:29
     if constexpr (sizeof(R) == 4) {
 #pragma clang fp contract(off)

@@ -7,10 +7,10 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 timeout -k 10 400 python3 bench.py --steps 2 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err || { echo bench failed; tail -5 $OUT/bench.err; exit 1; }
 cat $OUT/bench.json
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/stats_bench.json 2> $OUT/stats.err || { echo stats failed; tail -5 $OUT/stats.err; exit 1; }
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 bench.py --steps 2 --warmup 1 --no-extras > $OUT/stats_bench.json 2> $OUT/stats.err || { echo stats failed; tail -5 $OUT/stats.err; exit 1; }
 cat $OUT/stats_bench.json
-timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/fetch_bench.json 2> $OUT/fetch.err || { echo fetch failed; tail -5 $OUT/fetch.err; exit 1; }
-timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/write_bench.json 2> $OUT/write.err || { echo write failed; tail -5 $OUT/write.err; exit 1; }
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- python3 bench.py --steps 1 --warmup 0 --no-extras > $OUT/fetch_bench.json 2> $OUT/fetch.err || { echo fetch failed; tail -5 $OUT/fetch.err; exit 1; }
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python3 bench.py --steps 1 --warmup 0 --no-extras > $OUT/write_bench.json 2> $OUT/write.err || { echo write failed; tail -5 $OUT/write.err; exit 1; }
 find $OUT -name "*kernel_stats.csv" -exec cat {} \;
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections
