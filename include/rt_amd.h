@@ -21,7 +21,8 @@
 extern "C" {
 #endif
 
-#define RT_AMD_ABI_VERSION 2 /* 2: rt_render_params.s_end < 0 (not <= 0) means "all strata"; rt_render_multi */
+#define RT_AMD_ABI_VERSION 3 /* 2: rt_render_params.s_end < 0 (not <= 0) means "all strata"; rt_render_multi.  3: rt_scene_flatten_info / _stream take
+                                 reference_order; rt_scene_tune */
 
 /* ---- status codes ---------------------------------------------------------------------------- */
 enum {

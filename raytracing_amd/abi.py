@@ -10,7 +10,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-RT_AMD_ABI_VERSION = 2
+RT_AMD_ABI_VERSION = 3
 RT_TUNE_CANDIDATES = 6  # include/rt_amd.h
 RT_ALL_STRATA = -1
 
