@@ -226,13 +226,13 @@ int rt_abi_sizeof(const char *name);
 /* Flatten + upload a scene: replaces the construction of the reference's in-memory graph
  * (cpuRenderer.cpp:86-401 build it; bvh_node ctor bvh.h:15-41 is run by the host API before this). */
 int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out);
-/* rt_scene_upload with the float stream's bounding-volume hierarchy built ON THE DEVICE (Morton keys, radix sort, a
- * binary radix tree, boxes fitted bottom-up, the threaded stream written in place) instead of on the host: for scenes that
- * are rebuilt per frame.  Replaces bvh_node's constructor (bvh.h:15-41: longest axis of the node's box, std::sort, median split; the
+/* rt_scene_upload with the float stream's bounding-volume hierarchy built ON THE DEVICE instead of on the host: for scenes
+ * that are rebuilt per frame.  The device runs the host's own build (top-down binned surface-area heuristic, one kernel
+ * launch per tree level, boxes fitted bottom-up, the threaded stream written in place) with the host's arithmetic: the
+ * stream is the one rt_scene_upload makes (boundary sub-streams of general media may stand in another order behind the
+ * sentinel).  Replaces bvh_node's constructor (bvh.h:15-41: longest axis of the node's box, std::sort, median split; the
  * reference's CUDA tree builds on the device as well, src/cuda/bvh.h:140-188) for the production (f32) path; closest hits
- * do not depend on the hierarchy.  RT_ERR_UNSUPPORTED if a leaf of the scene is more than one record (an instance that
- * is neither emitted in world space -- spheres, triangles -- nor a translate / rotate_y of one box(); a constant_medium
- * whose boundary is not a static sphere): use rt_scene_upload. */
+ * do not depend on the hierarchy.  Every scene rt_scene_upload takes is taken (RT_ERR_UNSUPPORTED only for an empty world). */
 int rt_scene_upload_device_build(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out);
 void rt_scene_free(rt_scene *scene);
 /* out[4] = { threaded device nodes, lights, f32 device bytes, f64 device bytes (0 until a call first asks for

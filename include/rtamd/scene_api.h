@@ -1223,7 +1223,7 @@ class camera {
         for (rt_ctx *ctx : rtamd::sessions()) {
             rt_scene *scene = nullptr;
             // device_build (extension field; $RTAMD_DEVICE_BUILD sets it too): the hierarchy of the production stream is built
-            // on the GPU -- for scenes that are rebuilt per frame; scenes it does not take fall back to the host build
+            // on the GPU -- for scenes that are rebuilt per frame (the same stream as the host build's); an empty world falls back to the host path
             int rc = RT_ERR_UNSUPPORTED;
             if (device_build || getenv("RTAMD_DEVICE_BUILD")) rc = rt_scene_upload_device_build(ctx, &d, &scene);
             if (rc == RT_ERR_UNSUPPORTED) rc = rt_scene_upload(ctx, &d, &scene);

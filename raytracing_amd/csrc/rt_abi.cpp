@@ -149,61 +149,20 @@ template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, Device
     size_t built_units = 0; // device build: units the device wrote (tree, sentinel, sub-streams)
     int rc = device_build ? fl.run_leaves(leaves, box_pad, sub_begin) : fl.run();
     if (rc) return set_err(ctx, rc, err);
-    std::vector<size_t> top, rest; // device build: leaves ahead of the tree / leaves of the tree
-    size_t top_units = 0, rest_units = 0;
+    DeviceBuildKnobs dk; // device build: the host build's settings (the tuner's candidate, if any)
+    size_t leaves_units = 0;
     if (device_build) {
         if (leaves.empty()) return set_err(ctx, RT_ERR_UNSUPPORTED, "device build: the world holds no primitive");
-        // A Morton-ordered tree places a leaf by its centroid: one that spans most of the scene (final_scene's fog, a ground
-        // sphere, a room's walls) makes every ancestor up to the root as large as itself, and those boxes cull nothing.
-        // Such leaves go in FRONT of the tree, unboxed: while the largest remaining leaf has at least 0.3 of the area of the
-        // box round all remaining ones (at most eight times).  (Measured, ms per frame, host-built hierarchy / device-built before / after: final_scene 567 / 801 / 671, mesh_scene 443 / 605 / 489, first_scene 121 / 131 / 121, bounce frame 83 / 100 / 83.)
-        auto area = [](const double lo[3], const double hi[3]) {
-            const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-            return 2.0 * (dx * dy + dy * dz + dz * dx);
-        };
-        std::vector<char> is_top(leaves.size(), 0);
-        double top_share = 0.3; // (0.5: mesh_scene 602 ms, its walls stay in the tree; 0.3: 489; 0.2: the bounce frame 83 -> 90)
-        if (const char *e = dev_knob("RT_AMD_TOP_LEAF_SHARE")) top_share = std::atof(e); // development knob
-        for (int round = 0; round < 8 && !dev_knob("RT_AMD_NO_TOP_LEAVES"); round++) {
-            double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, best = -1;
-            size_t arg = 0, left = 0;
-            for (size_t k = 0; k < leaves.size(); k++) {
-                if (is_top[k]) continue;
-                left++;
-                for (int a = 0; a < 3; a++) {
-                    lo[a] = std::fmin(lo[a], leaves[k].lo[a]);
-                    hi[a] = std::fmax(hi[a], leaves[k].hi[a]);
-                }
-                const double ar = area(leaves[k].lo, leaves[k].hi);
-                // (only single records go in front: a leaf of several records -- an instance, a general medium -- holds positions
-                // that the device relocates when it places the leaf)
-                if (ar > best && leaves[k].n <= 5 && (dec_int(f.stream[(size_t)leaves[k].off + 1].w[3]) & 15) != K_MEDIUM_GEN) { best = ar; arg = k; }
-            }
-            if (left < 2 || !(best >= top_share * area(lo, hi))) break;
-            is_top[arg] = 1;
-        }
-        for (size_t k = 0; k < leaves.size(); k++) {
-            (is_top[k] ? top : rest).push_back(k);
-            (is_top[k] ? top_units : rest_units) += (size_t)leaves[k].n;
-        }
+        const BuildKnobs hk = knobs ? *knobs : BuildKnobs();
+        dk.bins = hk.bins; dk.order = hk.order; dk.thr2 = hk.thr2; dk.thrn = hk.thrn; dk.overlap = hk.overlap;
+        for (const auto &l : leaves) leaves_units += (size_t)l.n;
         leaf_units.swap(f.stream);
         leaf_cold.swap(f.cold);
         const size_t sub_units = leaf_units.size() - (size_t)sub_begin;
-        if (rest.empty() && sub_units) return set_err(ctx, RT_ERR_UNSUPPORTED, "device build: a general medium and no leaf for the tree");
-        const size_t total = top_units + (rest.empty() ? 2 : built_stream_units(rest_units, rest.size())) + sub_units; // an upper bound
+        const size_t total = built_stream_units(leaves_units, leaves.size()) + sub_units; // an upper bound
         if (total > (size_t(1) << 25)) return set_err(ctx, RT_ERR_NOMEM, "flattened scene too large");
-        f.stream.assign(total, UnitT<R>{}); // the device writes the tree's part of these two ranges
+        f.stream.assign(total, UnitT<R>{}); // the device writes these two ranges
         f.cold.assign(total, UnitT<R>{});
-        size_t at = 0;
-        for (size_t k : top)
-            for (int u = 0; u < leaves[k].n; u++, at++) {
-                f.stream[at] = leaf_units[(size_t)leaves[k].off + u];
-                f.cold[at] = leaf_cold[(size_t)leaves[k].off + u];
-            }
-        if (rest.empty()) { // nothing left for a tree: the sentinel (as Flattener::run writes it)
-            f.stream[at + 1].w[3] = enc_int(make_hdr(K_READY, 0), R(0));
-            f.cold[at].w[3] = enc_int(-1, R(0));
-        }
     }
     BlobBuilder b;
     size_t o_stream = b.add(f.stream), o_cold = b.add(f.cold);
@@ -223,22 +182,15 @@ template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, Device
                      sizeof(R) == 4 ? "f32" : "f64", t1 - t0, t2 - t1, ds.bytes, wall_ms() - t2);
     uint8_t *base = (uint8_t *)ds.blob;
     if constexpr (sizeof(R) == 4) {
-        if (device_build && !rest.empty()) {
+        if (device_build) {
             const double t3 = wall_ms();
-            std::vector<BuildLeaf> bl(rest.size());
-            float c_lo[3] = {INFINITY, INFINITY, INFINITY}, c_hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-            for (size_t j = 0; j < rest.size(); j++) {
-                const size_t k = rest[j];
-                bl[j].off = leaves[k].off;
-                bl[j].n = leaves[k].n;
+            std::vector<BuildLeaf> bl(leaves.size());
+            for (size_t k = 0; k < leaves.size(); k++) {
+                bl[k].off = leaves[k].off;
+                bl[k].n = leaves[k].n;
                 for (int a = 0; a < 3; a++) {
-                    cvt_lo(leaves[k].lo[a], bl[j].lo[a]);
-                    cvt_hi(leaves[k].hi[a], bl[j].hi[a]);
-                    const float c = 0.5f * (bl[j].lo[a] + bl[j].hi[a]);
-                    if (std::isfinite(c)) {
-                        c_lo[a] = std::fmin(c_lo[a], c);
-                        c_hi[a] = std::fmax(c_hi[a], c);
-                    }
+                    bl[k].lo[a] = leaves[k].lo[a];
+                    bl[k].hi[a] = leaves[k].hi[a];
                 }
             }
             BlobBuilder in; // what the build reads: leaf table, leaf stream, its cold units
@@ -249,14 +201,13 @@ template <class R> int upload_one(rt_ctx *ctx, const rt_scene_desc *desc, Device
             int built = 0;
             if (e == hipSuccess)
                 e = build_stream_on_device((const BuildLeaf *)((uint8_t *)d_in + o_bl), (int)bl.size(), (const UnitT<float> *)((uint8_t *)d_in + o_lu),
-                                           (const UnitT<float> *)((uint8_t *)d_in + o_lc), (int)rest_units, sub_begin, (int)(leaf_units.size() - (size_t)sub_begin),
-                                           (UnitT<float> *)(base + o_stream) + top_units, (UnitT<float> *)(base + o_cold) + top_units, c_lo, c_hi,
-                                           (float)box_pad, (int)top_units, &built);
+                                           (const UnitT<float> *)((uint8_t *)d_in + o_lc), sub_begin, (int)(leaf_units.size() - (size_t)sub_begin),
+                                           (UnitT<float> *)(base + o_stream), (UnitT<float> *)(base + o_cold), box_pad, dk, &built);
             (void)hipFree(d_in);
             HIP_TRY(ctx, e);
-            built_units = top_units + (size_t)built;
+            built_units = (size_t)built;
             if (built_units > f.stream.size()) return set_err(ctx, RT_ERR_HIP, "device build: the stream came out longer than its bound");
-            if (timing) std::fprintf(stderr, "[rt_amd timing] device build of %zu leaves (%zu ahead of the tree): %.2f ms\n", bl.size(), top.size(), wall_ms() - t3);
+            if (timing) std::fprintf(stderr, "[rt_amd timing] device build of %zu leaves: %.2f ms\n", bl.size(), wall_ms() - t3);
         }
     }
     SceneT<R> &s = ds.sc;

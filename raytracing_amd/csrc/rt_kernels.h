@@ -1713,6 +1713,10 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                 int fi = 0, fj = 0;
                 const int kind0 = tv.hdr & 15;
                 const unsigned long long midle = lane_mask(kind0 == K_IDLE);
+                // (tried: up to two / three items per trip -- an item that runs out in the middle of a trip followed by the next one
+                // in the SAME trip, so that the lanes that asked in vain do not sit out the trips up to the next shading trip, 5.6 of
+                // 64 lanes on a 1/8 range: the loop round this step costs more than those lanes bring, 514 -> 532 / 528 ms, 1/8
+                // range 68.7 -> 70.4 / 70.0 ms)
                 if (midle && units_left >= 0) {
                     if (units_left == 0) {
                         // the current item has no units left: take an accumulator slot none of whose paths is still in flight (the
