@@ -1550,6 +1550,11 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
             // its own `if (leaf_trip && mask)`: 622 -> 600 ms for the same instructions -- the code the compiler lays round
             // the loop's joins decides), run up to RT_LEAF_ROUNDS times per trip.  (A second step PER KIND for lanes that meet
             // the same kind again measured slower.)
+            // (Tried in round 3: each kind's block only says (hit, t, next), the closest hit updated and the cursor moved ONCE
+            // behind the four -- the copies hipcc lays at the joins of four blocks that each define the twelve registers of
+            // traversal state are a sixth of the kernel's static vector instructions: 3 814 -> 3 588 static VALU, 603 -> 460
+            // copies, and 514 -> 538 ms.  And the reverse: each block moving the cursor BEFORE its test, so that the test covers
+            // the next record's two LDS reads: 514 -> 518 ms.)
             auto leaf_round = [&](const int kind, const bool is_sph, const bool is_aab, const bool is_med, const bool is_oth,
                                   const unsigned long long ms, const unsigned long long ma, const unsigned long long mm,
                                   const unsigned long long mo) {
