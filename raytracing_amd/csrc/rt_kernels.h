@@ -251,6 +251,25 @@ template <class R> RT_DEV R medium_draw(R fifth, int node_id, int dup) {
 // The record stream lives in LDS (ALL_LDS: it fits, staged by stage_scene()) or in global memory, as a whole either way:
 // no per-load address-space branch.
 extern __shared__ __attribute__((aligned(16))) unsigned char rt_smem[];
+// The kernels here declare no static __shared__ data, so the dynamic array starts at LDS address 0 (checked at kernel entry:
+// lds_origin_check) and an offset into rt_smem IS the LDS address.  Addressing a record as rt_smem + offset costs one v_add of
+// the array's link-time address per fetch -- `v_add_u32 v8, 0, v86` in front of every ds_read of the BOX step --; as an absolute
+// LDS pointer the offset goes straight into the instruction.  (RT_LDS_ABS=0: the array's symbol, as before.)
+#ifndef RT_LDS_ABS
+#define RT_LDS_ABS 1
+#endif
+template <class T> RT_DEV const T *lds_at(unsigned off) {
+#if RT_LDS_ABS
+    return (const T *)(__attribute__((address_space(3))) const T *)(uintptr_t)off;
+#else
+    return reinterpret_cast<const T *>(rt_smem + off);
+#endif
+}
+RT_DEV void lds_origin_check() {
+#if RT_LDS_ABS
+    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
+#endif
+}
 
 template <class R> RT_DEV int ldi(R x) { return dec_int(x); }
 
@@ -276,9 +295,8 @@ template <class R, bool ALL_LDS> struct Mem {
     const UnitT<R> *glob;
     int lds_bytes;
     RT_DEV UnitT<R> ld(int pos) const {
-        const unsigned char *l = rt_smem + LdsLayout<R>::stream_off;
         if constexpr (ALL_LDS) {
-            return ld_unit(reinterpret_cast<const UnitT<R> *>(l + pos));
+            return ld_unit(lds_at<UnitT<R>>((unsigned)(LdsLayout<R>::stream_off + pos)));
         } else {
             // a stream that does not fit is read from global memory as a whole (its cache lines live in L2 / the vector L1):
             // a resident PREFIX with a per-load address-space branch measured slower than no prefix at all (mesh_scene 444 vs
@@ -301,7 +319,7 @@ template <class R, bool TAB_LDS> struct SceneV {
     uint32_t o_xforms, o_mats, o_texs, o_images, o_perlins, o_lights;
     int32_t n_lights, lights_is_list;
     template <class T> RT_DEV const T *at(uint32_t off) const {
-        if constexpr (TAB_LDS) return reinterpret_cast<const T *>(rt_smem + off);
+        if constexpr (TAB_LDS) return lds_at<T>(off);
         else return reinterpret_cast<const T *>(tab + off);
     }
     RT_DEV const XformT<R> &xform(int i) const { return at<XformT<R>>(o_xforms)[i]; }
@@ -351,6 +369,11 @@ RT_DEV bool box_hit(const UnitT<R> &u0, const UnitT<R> &u1, V3<R> o, V3<R> inv, 
         // as b * inv + (-o * inv).  inv is finite (inv_dir_trav): a ray parallel to the slab gets +-1e30-sized distances with
         // the signs of b - o, i.e. the axis passes exactly when the origin lies inside the slab, as in the reference.
         const rt_f2 tx = rt_f2{bx0, bx1} * inv.x + noi.x, ty = rt_f2{by0, by1} * inv.y + noi.y, tz = rt_f2{bz0, bz1} * inv.z + noi.z;
+        // (Calibration, round 3: two / four dummy vector instructions here -- +3.2 % / +6.4 % of the kernel's instructions, off
+        // the step's dependent chain -- cost +1.6 % / +1.9 % of the frame; taking the one v_add per record fetch out of the
+        // chain, 2.1 % of the instructions (lds_at), gained 0.3 %.  The vector unit is busy 96 % of the time AND the
+        // step's chain -- two LDS reads, fma, min, max3, compare, select, the next address -- is what a wave waits on:
+        // fewer instructions alone no longer buy time.)
         R tn = m_max(m_max(m_min(tx.x, tx.y), m_min(ty.x, ty.y)), m_max(m_min(tz.x, tz.y), tmin));
         // (tmax is the closest hit so far, a value the compiler cannot prove canonical: through fminf it would first be
         // quieted by a v_max_f32 x, x; the instruction itself needs no such thing)
@@ -1403,6 +1426,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
     float *const out = reinterpret_cast<float *>(out_);
     long long *const out64 = reinterpret_cast<long long *>(out_);
     static_assert(BLOCK == LdsLayout<R>::block, "LDS layout");
+    lds_origin_check();
     // Kernel arguments arrive as 8- and 16-dword scalar loads; left alone, the register allocator spills and reloads such a
     // tuple WHOLE (16 v_readlane for one pointer).  Passing every field through an empty asm makes each its own value.
     SceneV<R, TAB_LDS> sc = stage_scene<R, TAB_LDS>(sc_arg);
@@ -1962,6 +1986,7 @@ struct TraceArgs {
 template <class R, bool ALL_LDS, bool TAB_LDS, bool GEN_MEDIUM, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) trace_kernel(SceneT<R> sc_arg, const rt_ray *__restrict__ rays, const double *__restrict__ xi,
                                                       size_t n, rt_hit *__restrict__ out, TraceArgs a) {
+    lds_origin_check();
     const SceneV<R, TAB_LDS> sc = stage_scene<R, TAB_LDS>(sc_arg);
     const Mem<R, ALL_LDS> mem{sc_arg.stream, sc_arg.lds_units * Pos<R>::unit};
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
