@@ -129,23 +129,13 @@ def profiled_hbm_traffic():
     return None, None
 
 
-def partial_frame_bytes(W, H, n_strata):
-    """Algorithmic HBM bytes of one render_kernel launch: the sample range is cut into chunks (rt_abi.cpp plan_render: each
-    takes three quarters of what is left, minimum 32 -- two thirds / 16 below 360 strata) and every chunk writes a partial
-    frame of 64-bit cells, 24 B / pixel; a one-chunk launch writes the float frame itself, 12 B / pixel.  (The summing pass
-    then reads the partial frames once and writes the floats: another kernel.)"""
-    if n_strata <= 0:
-        return 0
-    min_chunk, pct = (32, 75) if n_strata >= 360 else (16, 67)
-    chunks, left = 0, n_strata
-    while left > 0:
-        take = max(left * pct // 100, min_chunk)
-        if take > left or left - take < min_chunk // 2:
-            take = left
-        left -= take
-        chunks += 1
+def partial_frame_bytes(W, H, n_chunks):
+    """Algorithmic HBM bytes of one render_kernel launch: the library cuts the sample range into chunks (rt_abi.cpp plan_render;
+    `sample_chunks` of rt_stats says how many) and every chunk writes a partial frame of 64-bit cells, 24 B / pixel; a one-chunk
+    launch writes the float frame itself, 12 B / pixel.  (The summing pass then reads the partial frames once and writes the
+    floats: another kernel.)"""
     cells = W * H * 3
-    return cells * 4 if chunks == 1 else chunks * cells * 8
+    return 0 if n_chunks <= 0 else (cells * 4 if n_chunks == 1 else n_chunks * cells * 8)
 
 
 def e2e_dropin(cfg, W, H, spp, depth, n_gpus, devices=None):
@@ -398,8 +388,9 @@ def run_rank(a, cfg, W, H, spp, depth, rank, world, dev, device, backend, groupe
             rays_local += int(ds_f.render_device(sc_f.camera, accum.data_ptr(), seed=1984, precision=abi.RT_PREC_F32, stream=stream, want_stats=True)["rays"])
             ds_f.close()
     else:
-        rays_local = int(ds.render_device(cam, accum.data_ptr(), seed=1984, s_begin=s0, s_end=s1, precision=abi.RT_PREC_F32, stream=stream,
-                                          want_stats=True)["rays"])
+        st_count = ds.render_device(cam, accum.data_ptr(), seed=1984, s_begin=s0, s_end=s1, precision=abi.RT_PREC_F32, stream=stream, want_stats=True)
+        rays_local = int(st_count["rays"])
+        launch_chunks = int(st_count["sample_chunks"])
     rays = sum_over_ranks(rays_local)
 
     if rank != 0:
@@ -469,7 +460,7 @@ def run_rank(a, cfg, W, H, spp, depth, rank, world, dev, device, backend, groupe
                      "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 5), "traffic": traffic,
                      "traffic_note": (f"HBM bytes per launch from the committed PMC passes ({traffic_src}); not collected live"
                                       if traffic else "HBM counters need their own profiler passes (profiles/)"),
-                     "algorithmic_bytes": None if anim else partial_frame_bytes(W, H, s1 - s0),
+                     "algorithmic_bytes": None if anim else partial_frame_bytes(W, H, launch_chunks), "sample_chunks": None if anim else launch_chunks,
                      "kernel": "render_kernel<float>", "kernel_ms": round(kern_ms, 3),
                      "flops_per_sample": round(cfg["flops"], 1),
                      "note": "non-MFMA FP32 vector roof (SURVEY 8d): the scene is cache-resident, HBM is not the bound"},

@@ -209,6 +209,8 @@ typedef struct rt_stats {
     uint64_t samples;   /* camera paths traced                                   */
     uint64_t rays;      /* ray_color invocations that traced a ray (R x samples) */
     double kernel_ms;   /* device time of the render kernels (hipEvent)          */
+    uint32_t sample_chunks; /* sample chunks the launch was cut into: each wrote a partial frame (1: straight into the caller's frame) */
+    uint32_t reserved;
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

@@ -83,7 +83,7 @@ class RenderParams(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("kernel_ms", C.c_double)]
+    _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("kernel_ms", C.c_double), ("sample_chunks", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 _ARRAYS = [("nodes", node_dtype), ("child_index", np.dtype("<i4")), ("spheres", sphere_dtype), ("quads", quad_dtype),

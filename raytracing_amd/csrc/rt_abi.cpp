@@ -328,10 +328,11 @@ int plan_render(rt_ctx *ctx, const rt_camera *cam, const rt_render_params *param
     } else {
         const int min_chunk = ctx->min_chunk > 0 ? ctx->min_chunk : (n_samples >= 360 ? 32 : 16);
         const int divisor = ctx->chunk_divisor > 1 ? ctx->chunk_divisor : (n_samples >= 360 ? 3 : 2); // (round 2's schedule: a third / a half of what is left)
-        // round 3: each chunk takes THREE QUARTERS of what is left (two thirds of a short range): 961 strata are 720 + 180 + 61
-        // instead of nine chunks -- a third of the partial frames to write and sum, and 0.7 % less time (517 -> 519 at 1/2, 519.0 at
-        // 3/4; a 1/8 range 70.3 -> 69.5 ms at 2/3); the kernel still ends on its shortest items
-        const int pct = ctx->chunk_pct > 0 ? ctx->chunk_pct : (ctx->chunk_divisor > 1 ? 0 : (n_samples >= 360 ? 75 : 67));
+        // round 3: each chunk takes 85 % of what is left: 961 strata are 816 + 123 + 22 instead of nine chunks, an 8-GPU rank's 120
+        // are 102 + 18 -- a third of the partial frames to write and sum; the kernel still ends on its shortest items.  (Whole
+        // frame: a third / a half / three quarters / 85 % / 90 % of what is left: 517 / 519 / 513.0 / 512.5 / 512.2 ms; a 1/8
+        // range at a half / two thirds / 85 % / one chunk: 70.3 / 68.6 / 67.8 / 69.8 ms; tools/ab.py with RT_AMD_CHUNKS.)
+        const int pct = ctx->chunk_pct > 0 ? ctx->chunk_pct : (ctx->chunk_divisor > 1 ? 0 : 85);
         rl.chunk_size = 0;
         n_chunks = 0;
         int at = s_begin;
@@ -434,6 +435,8 @@ int collect_stats(rt_ctx *ctx, const RenderPlan &pl, const unsigned long long *c
     stats->samples = (uint64_t)pl.n_px * (uint64_t)pl.n_samples;
     stats->rays = pl.n_samples > 0 ? c[0] : 0;
     stats->kernel_ms = pl.n_samples > 0 ? ms : 0.0;
+    stats->sample_chunks = (uint32_t)pl.n_chunks;
+    stats->reserved = 0;
     return RT_OK;
 }
 
@@ -857,6 +860,7 @@ int rt_render_multi(rt_ctx *const *ctxs, const rt_scene *const *scenes, int n_de
         total.samples += st.samples;
         total.rays += st.rays;
         if (st.kernel_ms > total.kernel_ms) total.kernel_ms = st.kernel_ms; // the devices run side by side
+        if (st.sample_chunks > total.sample_chunks) total.sample_chunks = st.sample_chunks;
     }
     // The exchange step: a binary tree over the contexts in a FIXED order (the frame repeats): at stride 1, 2, 4 ... context k
     // takes the sums of context k + stride -- a direct peer copy over xGMI into its staging buffer, then one add kernel, both

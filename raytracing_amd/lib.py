@@ -223,7 +223,7 @@ class DeviceScene:
         rc = self.ctx.L.rt_render(self.ctx.h, self.h, cam.ctypes.data, C.byref(p), accum.ctypes.data,
                                   rgb.ctypes.data if want_rgb8 else None, C.byref(st))
         self.ctx.check(rc, "rt_render")
-        return accum, rgb, {"samples": st.samples, "rays": st.rays, "kernel_ms": st.kernel_ms}
+        return accum, rgb, {"samples": st.samples, "rays": st.rays, "kernel_ms": st.kernel_ms, "sample_chunks": st.sample_chunks}
 
     def render_device(self, camera: np.ndarray, d_accum_ptr: int, seed: int = 0, s_begin: int = 0, s_end: int = abi.RT_ALL_STRATA,
                       precision: int = abi.RT_PREC_F32, sample_chunks: int = 0, stream: int = 0, want_stats: bool = False):
@@ -234,7 +234,7 @@ class DeviceScene:
         rc = self.ctx.L.rt_render_device(self.ctx.h, self.h, cam.ctypes.data, C.byref(p), d_accum_ptr, stream or None,
                                          C.byref(st) if want_stats else None)
         self.ctx.check(rc, "rt_render_device")
-        return {"samples": st.samples, "rays": st.rays, "kernel_ms": st.kernel_ms} if want_stats else None
+        return {"samples": st.samples, "rays": st.rays, "kernel_ms": st.kernel_ms, "sample_chunks": st.sample_chunks} if want_stats else None
 
     def render_static(self, camera: np.ndarray, d_accum_ptr: int, seed: int = 0, s_begin: int = 0,
                       s_end: int = abi.RT_ALL_STRATA, precision: int = abi.RT_PREC_F32, sample_chunks: int = 0, stream: int = 0):
@@ -266,4 +266,4 @@ def render_multi(scenes: list, camera: np.ndarray, seed: int = 0, s_begin: int =
     rc = root.L.rt_render_multi(ctxs, hs, n, cam.ctypes.data, C.byref(p), accum.ctypes.data,
                                 rgb.ctypes.data if want_rgb8 else None, C.byref(st))
     root.check(rc, "rt_render_multi")
-    return accum, rgb, {"samples": st.samples, "rays": st.rays, "kernel_ms": st.kernel_ms}
+    return accum, rgb, {"samples": st.samples, "rays": st.rays, "kernel_ms": st.kernel_ms, "sample_chunks": st.sample_chunks}
