@@ -1637,6 +1637,8 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                 }
                 RT_SUB_END(4, mo);
             };
+            // (tried: s_setprio per block -- BOX trips at priority 3: 512 -> 529 ms; leaf trips at 3: 525; shading trips at 3: 518.6 --
+            // the SIMD's own rotation between its four waves is the better arbiter)
             if (action == A_BOX) {
                 // a few BOX steps in a row while enough lanes stay at BOX records (amortises the block selection)
                 // (a BOX header is the integer 0: kind 0, no payload; one compare per step serves both the next step's lane
