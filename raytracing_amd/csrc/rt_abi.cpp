@@ -288,7 +288,8 @@ struct RenderPlan {
 // wastes lanes while its last paths finish) and the kernel ends on short ones (the end-of-kernel imbalance is one short item
 // per wave).  params->sample_chunks > 0 forces that many equal chunks instead.  max_chunks caps the number of chunks (the
 // partial frames must fit where the caller keeps them).
-int plan_render(rt_ctx *ctx, const rt_camera *cam, const rt_render_params *params, int max_chunks, RenderPlan &pl) {
+// (scene: for the chunk schedule -- a stream read from global memory wants longer middle chunks; may be null)
+int plan_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_params *params, int max_chunks, RenderPlan &pl) {
     if (cam->image_width <= 0 || cam->image_height <= 0 || cam->sqrt_spp <= 0 || cam->max_depth < 0)
         return set_err(ctx, RT_ERR_INVALID, "render: bad camera");
     if ((int64_t)cam->image_width * cam->image_height > (int64_t)1 << 28) return set_err(ctx, RT_ERR_INVALID, "render: image too large");
@@ -332,7 +333,10 @@ int plan_render(rt_ctx *ctx, const rt_camera *cam, const rt_render_params *param
         // are 102 + 18 -- a third of the partial frames to write and sum; the kernel still ends on its shortest items.  (Whole
         // frame: a third / a half / three quarters / 85 % / 90 % of what is left: 517 / 519 / 513.0 / 512.5 / 512.2 ms; a 1/8
         // range at a half / two thirds / 85 % / one chunk: 70.3 / 68.6 / 67.8 / 69.8 ms; tools/ab.py with RT_AMD_CHUNKS.)
-        const int pct = ctx->chunk_pct > 0 ? ctx->chunk_pct : (ctx->chunk_divisor > 1 ? 0 : 85);
+        // A stream that is read from global memory (mesh_scene) takes three quarters: its 484 strata as 411 + 41 + 32 cost 324-338
+        // ms against 297-304 as 363 + 91 + 30 -- short items cost such a stream more, so fewer samples should sit in them.
+        const bool resident = !scene || scene->f32.sc.lds_units > 0;
+        const int pct = ctx->chunk_pct > 0 ? ctx->chunk_pct : (ctx->chunk_divisor > 1 ? 0 : (resident ? 85 : 75));
         rl.chunk_size = 0;
         n_chunks = 0;
         int at = s_begin;
@@ -341,7 +345,11 @@ int plan_render(rt_ctx *ctx, const rt_camera *cam, const rt_render_params *param
             int left = s_end - at, take = pct > 0 ? (int)((int64_t)left * pct / 100) : left / divisor;
             if (ctx->max_chunk > 0 && take > ctx->max_chunk) take = ctx->max_chunk;
             if (take < min_chunk) take = min_chunk;
-            if (take > left || left - take < min_chunk / 2 || n_chunks == sched_cap - 1) take = left;
+            // (what would be left is too short for a chunk of its own: it joins this one -- unless that makes the LAST chunk a long
+            // one: mesh_scene's 484 strata as 411 + 73 took 327-338 ms against 301-304 as 363 + 91 + 30; the kernel has to end on
+            // short items)
+            if (take < left && left - take < min_chunk / 2) take = left > 2 * min_chunk ? left - min_chunk : left;
+            if (take > left || n_chunks == sched_cap - 1) take = left;
             at += take;
             rl.chunk_start[++n_chunks] = at;
         }
@@ -725,7 +733,7 @@ int rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
                      float *d_accum, void *stream_, rt_stats *stats) {
     if (!ctx || !scene || !cam || !params || !d_accum) return set_err(ctx, RT_ERR_INVALID, "rt_render_device: null argument");
     RenderPlan pl;
-    int rc = plan_render(ctx, cam, params, 65535, pl);
+    int rc = plan_render(ctx, scene, cam, params, 65535, pl);
     if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -760,7 +768,7 @@ int rt_render_static(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, c
         return set_err(ctx, RT_ERR_INVALID, "rt_render_static: the f64 stream of this scene is built (and allocated) by the first "
                                             "RT_PREC_F64 call of rt_render_device / rt_trace_batch; make that call first");
     RenderPlan pl;
-    int rc = plan_render(ctx, cam, params, (int)std::min<size_t>(max_chunks, 65535), pl); // (0 or 1: a single chunk)
+    int rc = plan_render(ctx, scene, cam, params, (int)std::min<size_t>(max_chunks, 65535), pl); // (0 or 1: a single chunk)
     if (rc) return rc;
     if (partial_bytes_of(pl, params->precision, true) > room) // (cannot happen: the plan honours its cap)
         return set_err(ctx, RT_ERR_INVALID, "rt_render_static: " + std::to_string(partial_bytes_of(pl, params->precision, true)) +
@@ -825,7 +833,7 @@ int rt_render_multi(rt_ctx *const *ctxs, const rt_scene *const *scenes, int n_de
             if (ctxs[j] == ctxs[k]) // a context's buffers, counters and events serve one launch at a time
                 return set_err(root, RT_ERR_INVALID, "rt_render_multi: the same context is listed twice (create one per entry)");
     RenderPlan whole;
-    int rc = plan_render(root, cam, params, 65535, whole); // validates the camera and the range once
+    int rc = plan_render(root, scenes[0], cam, params, 65535, whole); // validates the camera and the range once
     if (rc) return rc;
     const int s_begin = whole.rl.s_begin, n_samples = whole.n_samples;
     const size_t n_px = whole.n_px, bytes = n_px * 3 * sizeof(float);
@@ -840,7 +848,7 @@ int rt_render_multi(rt_ctx *const *ctxs, const rt_scene *const *scenes, int n_de
         rt_render_params p = *params;
         p.s_begin = s_begin + (int)(((int64_t)k * n_samples) / n_devices);
         p.s_end = s_begin + (int)(((int64_t)(k + 1) * n_samples) / n_devices);
-        if ((rc = plan_render(c, cam, &p, 65535, plans[k])) != RT_OK) return fail_from(k, rc);
+        if ((rc = plan_render(c, scenes[k], cam, &p, 65535, plans[k])) != RT_OK) return fail_from(k, rc);
         if (hipSetDevice(c->device) != hipSuccess) return fail_from(k, set_err(c, RT_ERR_HIP, "hipSetDevice failed"));
         if (params->precision == RT_PREC_F64 && (rc = need_f64(c, scenes[k])) != RT_OK) return fail_from(k, rc);
         if ((rc = ensure(c, (void **)&c->accum, &c->accum_bytes, bytes)) != RT_OK) return fail_from(k, rc);
