@@ -1747,7 +1747,8 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                 // (tried: up to two / three items per trip -- an item that runs out in the middle of a trip followed by the next one
                 // in the SAME trip, so that the lanes that asked in vain do not sit out the trips up to the next shading trip, 5.6 of
                 // 64 lanes on a 1/8 range: the loop round this step costs more than those lanes bring, 514 -> 532 / 528 ms, 1/8
-                // range 68.7 -> 70.4 / 70.0 ms)
+                // range 68.7 -> 70.4 / 70.0 ms; only in the kernels that read the stream from global memory, where a quarter of the trips
+                // run after an item's last unit was dealt: mesh_scene 299 -> 302-311 / 300-308 ms)
                 if (midle && units_left >= 0) {
                     if (units_left == 0) {
                         // the current item has no units left: take an accumulator slot none of whose paths is still in flight (the
