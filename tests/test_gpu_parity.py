@@ -141,16 +141,21 @@ def test_frame_f64_matches_oracle_path_for_path(scenes, n):
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 6])
 def test_frame_f32_tracks_oracle(scenes, n):
-    """float paths follow the double oracle's paths except where rounding flips a branch: most pixels agree to 1e-4."""
+    """float paths follow the double oracle's paths except where rounding flips a branch -- a path whose float copy takes the
+    other side of a test (a grazing hit, a Fresnel draw at the threshold) ends elsewhere and its pixel differs.  Measured share
+    of values within 1e-4 (relative) of the oracle's: 0.995 / 0.992 / 0.955 / 0.997 / 0.999 for scenes 1 / 2 / 3 / 4 / 6 (final_scene's
+    fog and glass flip most); the floor below is that minus a point.  The median deviation is rounding only: <= 5e-7 measured."""
+    floor = {1: 0.985, 2: 0.98, 3: 0.94, 4: 0.985, 6: 0.99}[n]
     sc = fx.scene(n)
     cam, _, _, _ = fx.img(n)
     cam = fx.with_size(cam, sqrt_spp=4, max_depth=12)
     want, cnt = O.render(sc, cam, seed=3, rng_mode=1, threads=8)
     acc, rgb, st = scenes[n].render(cam, seed=3, precision=abi.RT_PREC_F32)
-    assert abs(st["rays"] - int(cnt[4])) <= 0.02 * int(cnt[4])
+    assert abs(st["rays"] - int(cnt[4])) <= 0.005 * int(cnt[4])
     rel = np.abs(acc.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-3)
     ok = np.isfinite(rel)
-    assert np.mean(rel[ok] < 1e-4) >= 0.90
+    assert np.mean(rel[ok] < 1e-4) >= floor, float(np.mean(rel[ok] < 1e-4))
+    assert np.median(rel[ok]) <= 2e-6, float(np.median(rel[ok]))
     assert np.isnan(acc).sum() <= np.isnan(want).sum() + 3
 
 
