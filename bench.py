@@ -105,9 +105,38 @@ def cpu_baseline(scene_id, cores_all):
         legs.append({"threads": threads, "msamples_per_s": round(W * H * spp / dt / 1e6, 4),
                      "sample": f"{name} {W}x{H}, {spp} spp, depth 50 ({W * H * spp} samples, {dt:.1f} s wall)"})
     best = max(legs, key=lambda l: l["msamples_per_s"])
-    return {"value": best["msamples_per_s"], "unit": "Msamples/s", "cores": best["threads"], "kind": "port",
-            "sample": best["sample"], "legs": legs, "host_cpus_visible": os.cpu_count(),
-            "note": "oracle/liboracle.so (the pinned CPU restatement) on this box's host cores; best of {1, cores} threads"}
+    out = {"value": best["msamples_per_s"], "unit": "Msamples/s", "cores": best["threads"], "kind": "port",
+           "sample": best["sample"], "legs": legs, "host_cpus_visible": os.cpu_count(),
+           "note": "oracle/liboracle.so (the pinned CPU restatement) on this box's host cores; best of {1, cores} threads"}
+    ref = reference_leg(scene_id)
+    if ref:
+        out["reference"] = ref
+    return out
+
+
+def reference_leg(scene_id, W=160, H=90, spp=144):
+    """The COMPILED REFERENCE itself beside the port, when its binary travelled with the tree (oracle/_ref/refgen: the
+    reference's own get_ray / ray_color from its headers, built in the build container by oracle/Makefile): one thread -- its
+    OpenMP build anti-scales -- on a bounded sample.  final_scene and cornell_box only (mesh_scene reads the
+    reference's own shapes directory, which does not travel).  None when the binary is absent or fails."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "refgen")
+    if scene_id not in (1, 2, 3) or not os.access(exe, os.X_OK):
+        return None
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            os.makedirs(os.path.join(tmp, "images"), exist_ok=True)
+            env = dict(os.environ, RTW_IMAGES=os.path.join(ROOT, "raytracing_amd", "assets"), OMP_NUM_THREADS="1")
+            t0 = time.time()
+            r = subprocess.run([exe, "render_nocheck", str(scene_id), str(W), str(H), str(spp), "50", "1", os.path.join(tmp, "frame.bin"), "1"],
+                               cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+            dt = time.time() - t0
+        if r.returncode != 0:
+            return None
+        return {"kind": "reference", "threads": 1, "msamples_per_s": round(W * H * spp / dt / 1e6, 4),
+                "sample": f"scene {scene_id} {W}x{H}, {spp} spp, depth 50 ({W * H * spp} samples, {dt:.1f} s wall, scene build included)",
+                "note": "oracle/_ref/refgen render_nocheck: the reference's own headers compiled with g++ -O2, glibc rand"}
+    except Exception:
+        return None
 
 
 def profiled_hbm_traffic():

@@ -41,3 +41,18 @@ def test_two_rank_spp_split_matches_single(tmp_path):
     cam, _, _, _ = fx.img(2)
     whole, _ = O.render(sc, cam, seed=11, rng_mode=1)
     np.testing.assert_allclose(got, whole.reshape(-1), rtol=1e-5, atol=1e-6)
+
+
+def test_bench_reference_leg_times_the_compiled_reference():
+    """bench.py's cpu_baseline carries, beside the port, the compiled reference itself (oracle/_ref/refgen) when the binary is
+    there: a tiny cornell_box sample here; absent binary -> None, never an error."""
+    import os
+
+    import bench
+    exe = os.path.join(bench.ROOT, "oracle", "_ref", "refgen")
+    leg = bench.reference_leg(2, 32, 18, 16)
+    if not os.access(exe, os.X_OK):
+        assert leg is None
+        return
+    assert leg is not None and leg["kind"] == "reference" and leg["threads"] == 1 and leg["msamples_per_s"] > 0
+    assert bench.reference_leg(4) is None  # (mesh_scene needs the reference's own shapes directory)
