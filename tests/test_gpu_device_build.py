@@ -84,6 +84,26 @@ def test_device_built_stream_structure_and_hits(gpu_ctx, n):
         host.close()
 
 
+def test_device_build_large_scene_equals_host_stream(gpu_ctx):
+    """20 000 spheres (+ the random scene's quads, triangles, media, instances): fifteen-odd tree levels, nodes of every size
+    from the root's 20 000 leaves down; the device-built stream is still the host's, bit for bit."""
+    sc = random_scene.build(7, n_spheres=20000)
+    ds = gpu_ctx.upload(sc, device_build=True)
+    try:
+        units, ids = ds.download_stream()
+        h_units, h_ids = lib.flatten_stream(sc)
+        recs = stream_check.records(units)
+        end = next(i for i, k in recs if k == 15) + 2
+        assert len(units) == len(h_units) and (np.asarray(ids[:end]) == np.asarray(h_ids[:end])).all()
+        du, hu = units[:end].view(np.int32).copy(), h_units[:end].view(np.int32).copy()
+        for i, k in recs:
+            if i < end and k == 9:
+                du[i, 0] = hu[i, 0] = 0
+        assert (du == hu).all()
+    finally:
+        ds.close()
+
+
 def test_device_build_single_primitive_and_double_path(gpu_ctx):
     """one leaf: no tree at all; and the double (parity) stream of a device-built scene is still the reference's order"""
     sc = random_scene.build(3, n_spheres=0, single_records=True)
