@@ -150,7 +150,7 @@ def profiled_hbm_traffic():
     for path in sorted(paths, key=lambda p: (os.path.basename(p)[:3], "_final_" in os.path.basename(p), os.path.basename(p)), reverse=True):
         try:
             for line in open(path):
-                if "render_kernel" in line:
+                if "render_kernel" in line and not line.lstrip().startswith("#"):
                     c = ast.literal_eval(line[line.index("{"):].strip())
                     return int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), os.path.relpath(path, ROOT)
         except (OSError, ValueError, KeyError, SyntaxError):

@@ -56,3 +56,16 @@ def test_bench_reference_leg_times_the_compiled_reference():
         return
     assert leg is not None and leg["kind"] == "reference" and leg["threads"] == 1 and leg["msamples_per_s"] > 0
     assert bench.reference_leg(4) is None  # (mesh_scene needs the reference's own shapes directory)
+
+
+def test_bench_reads_the_latest_committed_hbm_counters():
+    """roofline.traffic comes from the newest round's committed PMC summary (2 x FETCH_SIZE + WRITE_SIZE of the render kernel's
+    line, KB per launch); a comment that names the kernel must not derail the parser."""
+    import glob
+    import os
+
+    import bench
+    got = bench.profiled_hbm_traffic()
+    newest = sorted(os.path.basename(p)[:3] for p in glob.glob(os.path.join(bench.ROOT, "profiles", "r*_hbm_counters.txt")))[-1]
+    assert got is not None and os.path.basename(got[1]).startswith(newest), got
+    assert 50e6 < got[0] < 5e9
