@@ -1244,13 +1244,15 @@ template <int OFF> RT_DEV V3<float> kernarg_load_background() {
 // term, beta * (emitted | background), which is L).
 template <class R, bool ALL_LDS, class SC>
 RT_DEV bool shade_hit(const Mem<R, ALL_LDS> &mem, const SC &sc, const V3<R> &background, const RayT<R> &ray, R best_t, int best_off,
-                      const V3<R> &beta, V3<R> &L, Hit<R> &h) {
+                      const V3<R> &beta, V3<R> &L, Hit<R> &h, int &mat_noise) {
+    mat_noise = -1;
     if (best_off < 0) { // camera.h:300
         L = beta * background;
         return false;
     }
     h = finalize(mem, sc, ray, best_t, best_off, false);
     const MatT<R> m = sc.mat(h.mat);
+    mat_noise = m.noise; // (for the caller's noise-texture step: one word of the record that is read here anyway)
     if (m.kind == RT_MAT_DIFFUSE_LIGHT) { // material.h:129
         V3<R> emitted = mk<R>(R(0), R(0), R(0));
         if (h.front) emitted = tex_value(sc, m.tex, h.u, h.v, h.p);
@@ -1727,6 +1729,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                 h.p = mk<R>(R(0), R(0), R(0));
                 h.mat = 0;
                 bool scatter = false;
+                int mat_noise = -1;
                 if (ready) {
                     if constexpr (sizeof(R) == 4) { // traversal ended in the world frame: tv holds the world-space ray
                         ray.o = tv.o;
@@ -1735,7 +1738,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                     V3<R> L, background;
                     if constexpr (cam_at_use) background = kernarg_load_background<KA_CAM>();
                     else background = ld3(cam.background);
-                    scatter = shade_hit(mem, sc, background, ray, tv.best_t, tv.best_off, beta, L, h);
+                    scatter = shade_hit(mem, sc, background, ray, tv.best_t, tv.best_off, beta, L, h, mat_noise);
                     if (!scatter) add_sample(L);
                 }
                 RT_SH_END(0, ready);
@@ -1848,7 +1851,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneT<R> sc_arg, CameraT
                 bool has_turb = false;
                 R turb = R(0);
                 if constexpr (sizeof(R) == 4 && RT_WAVE_NOISE) {
-                    const int noise_idx = scatter ? sc.mat(h.mat).noise : -1; // (one word of the material the hit record named)
+                    const int noise_idx = scatter ? mat_noise : -1; // (one word of the material record shade_hit read)
                     unsigned long long mn = lane_mask(noise_idx >= 0);
                     while (mn) { // wave-uniform
                         const int src = __builtin_ctzll(mn);
