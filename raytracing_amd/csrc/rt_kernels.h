@@ -809,6 +809,9 @@ RT_DEV Hit<R> finalize(const Mem<R, ALL_LDS> &mem, const SC &sc, const RayT<R> &
             h.p = ray_at(rb, best_t);
         }
         // which face: the slab plane whose distance is the winning t
+        // (tried: the plane whose coordinate is closest to the hit POINT's -- six differences instead of six subtract-multiply-
+        // compare probes and three reciprocals: final_scene 510.6 -> 509.2 ms, and 197 more of the 6 694 rays aimed at box edges
+        // and corners name the neighbouring face (all ties); the distance names the reference's face there: kept)
         const V3<R> inv = inv_dir(rb.d);
         int face = 0;
         R err = Const<R>::inf;
