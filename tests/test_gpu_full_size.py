@@ -73,6 +73,8 @@ def test_partial_frame_repeats_bit_for_bit(headline):
     assert a.tobytes() == b.tobytes(), f"{int((a != b).sum())} of {a.size} values differ between two runs"
     c, _, sc_ = ds.render(scene.camera, seed=7, s_begin=s0, s_end=s1, precision=abi.RT_PREC_F32, sample_chunks=5, want_rgb8=False)
     assert sc_["rays"] == sa["rays"] and c.tobytes() == a.tobytes(), "the cut into sample chunks must not show either"
+    # rt_stats says how the library cut the range: its own decreasing schedule (a few chunks), and the caller's five
+    assert 2 <= sa["sample_chunks"] <= 4 and sc_["sample_chunks"] == 5, (sa["sample_chunks"], sc_["sample_chunks"])
 
 
 def test_full_frame_downsampled_matches_converged_reference(headline, whole):
