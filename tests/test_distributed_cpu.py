@@ -43,6 +43,17 @@ def test_two_rank_spp_split_matches_single(tmp_path):
     np.testing.assert_allclose(got, whole.reshape(-1), rtol=1e-5, atol=1e-6)
 
 
+def test_split_range_partitions_for_every_world_size():
+    """1, 2, 4, 8 ... ranks (and more ranks than strata): the ranges are contiguous, disjoint, exhaustive, sizes within one."""
+    for n in (961, 484, 9, 1, 0):
+        for world in (1, 2, 3, 4, 8, 16, 1024):
+            parts = [split_range(n, world, r) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            sizes = [b - a for a, b in parts]
+            assert min(sizes) >= 0 and max(sizes) - min(sizes) <= 1
+
+
 def test_bench_reference_leg_times_the_compiled_reference():
     """bench.py's cpu_baseline carries, beside the port, the compiled reference itself (oracle/_ref/refgen) when the binary is
     there: a tiny cornell_box sample here; absent binary -> None, never an error."""
